@@ -1,0 +1,159 @@
+/*
+ * pylda_hip.h - C ABI of libpylda_hip.so: the MI355X (gfx950) implementation
+ * of PyLDA's variational-Bayes E-step hot path.
+ *
+ * The reference (kzhai/PyLDA) has no FFI: its seam is two Python methods,
+ * VariationalBayes.e_step (variational_bayes.py:132-216) and m_step
+ * (:218-235), driven by learning() (:239-261) and inference() (:263-271).
+ * Each entry point below names the reference lines it replaces.  The Python
+ * binding that calls these (ctypes) is pylda_amd/_capi.py; the stub a
+ * maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; the caller owns every host buffer; the library
+ *    never keeps a host pointer after the call returns;
+ *  - matrices handed over by the host use numpy's C order: eta and sstats
+ *    are (K, V) row-major, gamma is (D, K) row-major;
+ *  - every function returns 0 on success or a negative pylda_status; the
+ *    text of the last failure is pylda_last_error(ctx) (or (NULL) for
+ *    failures of pylda_create); no C++ exception crosses the ABI;
+ *  - a context is used from one thread at a time (ctypes drops the GIL for
+ *    the duration of a call); work is enqueued on the context's HIP stream
+ *    and the *_get_* / *_results functions synchronise it;
+ *  - there is no CPU fallback: without a usable HIP device pylda_create
+ *    fails with PYLDA_ERR_HIP.
+ */
+#ifndef PYLDA_HIP_H
+#define PYLDA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pylda_ctx pylda_ctx;
+typedef struct pylda_corpus pylda_corpus;
+
+typedef enum pylda_status {
+    PYLDA_OK = 0,
+    PYLDA_ERR_INVALID = -1, /* bad argument (shape, range, NULL, unsorted CSR ...) */
+    PYLDA_ERR_HIP = -2,     /* HIP runtime error (no device, launch failure ...)   */
+    PYLDA_ERR_OOM = -3,     /* host or device allocation failed                    */
+    PYLDA_ERR_STATE = -4    /* call sequence error (e.g. results before an e-step) */
+} pylda_status;
+
+/* Library version string, e.g. "pylda_hip 0.1 (gfx950)". */
+const char* pylda_version(void);
+
+/* Number of visible HIP devices (0 is a valid answer, not an error). */
+int pylda_device_count(int* count);
+
+/* Create a context for a model with K topics over V word types on `device`.
+ * Allocates the device-resident tables (eta, exp(E_log_eta), sstats: K*V
+ * doubles each).  Replaces the per-call numpy allocations of
+ * variational_bayes.py:147-152. */
+int pylda_create(int device, int K, int V, pylda_ctx** out);
+void pylda_destroy(pylda_ctx* ctx);
+const char* pylda_last_error(const pylda_ctx* ctx);
+
+/* Run the context's work on an existing HIP stream (e.g. torch's current
+ * stream, so that an RCCL all-reduce issued through torch.distributed is
+ * ordered after the E-step without a host sync).  NULL restores the
+ * context's own stream.  The caller keeps the stream alive. */
+int pylda_set_stream(pylda_ctx* ctx, void* hip_stream);
+int pylda_synchronize(pylda_ctx* ctx);
+
+/* Upload a parsed corpus: the (word_ids, word_cts) lists parse_data builds
+ * (variational_bayes.py:98-130) flattened to CSR.  doc_ptr has D+1 entries,
+ * term ids are in [0, V), counts are >= 1, ids are unique within a document
+ * (parse_data builds them from a dict).  Copies to the device once and
+ * builds the launch schedule (documents bucketed by distinct-term count). */
+int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr,
+                        const int32_t* term_id, const int32_t* term_ct, pylda_corpus** out);
+void pylda_corpus_destroy(pylda_corpus* corpus);
+/* D, nnz, token total, largest distinct-term count. */
+int pylda_corpus_info(const pylda_corpus* corpus, int64_t* D, int64_t* nnz, int64_t* tokens,
+                      int32_t* max_terms);
+
+/* Model state.  eta is self._eta (K, V) (variational_bayes.py:95,226);
+ * alpha is self._alpha_alpha (K,) (inferencer.py:57). */
+int pylda_set_eta(pylda_ctx* ctx, const double* eta_kv);
+int pylda_get_eta(pylda_ctx* ctx, double* eta_kv);
+int pylda_set_alpha(pylda_ctx* ctx, const double* alpha_k);
+
+/* THE HOT PATH: one E-step over `corpus` (variational_bayes.py:132-216).
+ *   max_iter / tol  local_parameter_iteration / _converge_threshold (:132)
+ *   heldout         0: training mode (parsed_corpus == None): accumulates the
+ *                      sufficient statistics (:207);
+ *                   1: held-out mode (:154-155, :202-204): word log-likelihood,
+ *                      no sufficient statistics.
+ * Asynchronous: enqueues compute_dirichlet_expectation (inferencer.py:15-18),
+ * the per-document phi/gamma loop and the reductions on the context's
+ * stream.  Results stay on the device until fetched. */
+int pylda_estep(pylda_ctx* ctx, pylda_corpus* corpus, int max_iter, double tol, int heldout);
+
+/* Corpus-level scalars of the last E-step (synchronises):
+ * document_log_likelihood (:143,:195-199), words_log_likelihood (:144,:204)
+ * and how many documents were finished by the log-space safety-net kernel. */
+int pylda_estep_results(pylda_ctx* ctx, pylda_corpus* corpus, double* document_log_likelihood,
+                        double* words_log_likelihood, int64_t* logspace_documents);
+
+/* phi_sufficient_statistics (K, V) of the last training-mode E-step (:214). */
+int pylda_get_sstats(pylda_ctx* ctx, double* sstats_kv);
+/* gamma_values (D, K) of the last E-step over `corpus` (:213,:216). */
+int pylda_get_gamma(pylda_ctx* ctx, pylda_corpus* corpus, double* gamma_dk);
+/* Per-document values (any pointer may be NULL): the document's own terms of
+ * :195-199, of :204, and the number of inner iterations it ran. */
+int pylda_get_doc_values(pylda_ctx* ctx, pylda_corpus* corpus, double* doc_ll,
+                         double* doc_words_ll, int32_t* iters);
+
+/* One-shot host-buffer form of the hot path (the signature SURVEY.md 8b
+ * proposes): set_alpha + set_eta + estep + fetch.  Output pointers may be
+ * NULL.  scalars_out[0] = document_log_likelihood, [1] = words_log_likelihood. */
+int pylda_estep_host(pylda_ctx* ctx, pylda_corpus* corpus, const double* alpha_k,
+                     const double* eta_kv, int max_iter, double tol, int heldout,
+                     double* gamma_dk, double* sstats_kv, double* doc_ll, double* doc_words_ll,
+                     int32_t* iters, double* scalars_out);
+
+/* Device-resident views for multi-GPU data parallelism: the sufficient
+ * statistics live word-major, (V, K) doubles.  The Python side wraps this
+ * pointer (zero-copy) and all-reduces it over RCCL between e_step and
+ * m_step; elements = K*V.  Also the gamma buffer of a corpus (D, K). */
+void* pylda_sstats_device(pylda_ctx* ctx);
+void* pylda_eta_device(pylda_ctx* ctx);      /* (K, V) doubles, numpy layout */
+void* pylda_gamma_device(pylda_corpus* corpus);
+
+/* Tell the library that the caller wrote eta (have_eta = 1) and/or the
+ * sufficient statistics (have_sstats = 1) through the device pointers above
+ * (e.g. after an all-reduce); -1 leaves a flag unchanged. */
+int pylda_mark_device_state(pylda_ctx* ctx, int have_eta, int have_sstats);
+
+/* Device M-step (variational_bayes.py:218-235) on the resident buffers:
+ * topic log-likelihood from the PRE-update eta (:222-224), eta <- sstats +
+ * beta (:226), alpha sufficient statistics from the gamma of `corpus`
+ * (:232-233).  beta_v is self._alpha_beta (V,).  alpha_ss_k may be NULL. */
+int pylda_mstep(pylda_ctx* ctx, pylda_corpus* corpus, const double* beta_v,
+                double* topic_log_likelihood, double* alpha_ss_k);
+
+/* Profiling: when enabled, every pylda_estep brackets its document kernels
+ * with HIP events on the launch stream.  pylda_kernel_time returns the
+ * accumulated document-kernel time (ms) and launch count since the last
+ * reset, and resets them. */
+int pylda_set_profiling(pylda_ctx* ctx, int enabled);
+int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, int64_t* estep_calls);
+
+/* Tuning / test options:
+ *   "force_logspace" 0|1  run every document through the log-space
+ *                         safety-net kernel (the reference's formulation);
+ *   "force_variant"  -1 (automatic) or a kernel variant index. */
+int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value);
+
+/* Test hook: evaluate the device special functions on n host values. */
+int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digamma_out,
+                       double* lgamma_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYLDA_HIP_H */

@@ -1,0 +1,275 @@
+"""ctypes binding of libpylda_hip.so (the C ABI in include/pylda_hip.h).
+
+This is the only place Python touches the native library.  There is no CPU
+fallback anywhere in pylda_amd: if the shared library is missing, or no HIP
+device is visible, the failure is raised here, loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpylda_hip.so")
+_lib = None
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int32_p = ctypes.POINTER(ctypes.c_int32)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/pylda_hip.h declares
+SIGNATURES = {
+    "pylda_version": (ctypes.c_char_p, []),
+    "pylda_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "pylda_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    "pylda_destroy": (None, [_vp]),
+    "pylda_last_error": (ctypes.c_char_p, [_vp]),
+    "pylda_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "pylda_synchronize": (ctypes.c_int, [_vp]),
+    "pylda_corpus_create": (ctypes.c_int, [_vp, ctypes.c_int64, _c_int64_p, _c_int32_p, _c_int32_p,
+                                           ctypes.POINTER(_vp)]),
+    "pylda_corpus_destroy": (None, [_vp]),
+    "pylda_corpus_info": (ctypes.c_int, [_vp, _c_int64_p, _c_int64_p, _c_int64_p, _c_int32_p]),
+    "pylda_set_eta": (ctypes.c_int, [_vp, _c_double_p]),
+    "pylda_get_eta": (ctypes.c_int, [_vp, _c_double_p]),
+    "pylda_set_alpha": (ctypes.c_int, [_vp, _c_double_p]),
+    "pylda_estep": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
+    "pylda_estep_results": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, _c_int64_p]),
+    "pylda_get_sstats": (ctypes.c_int, [_vp, _c_double_p]),
+    "pylda_get_gamma": (ctypes.c_int, [_vp, _vp, _c_double_p]),
+    "pylda_get_doc_values": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, _c_int32_p]),
+    "pylda_estep_host": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_int, _c_double_p, _c_double_p,
+                                        _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
+    "pylda_sstats_device": (_vp, [_vp]),
+    "pylda_eta_device": (_vp, [_vp]),
+    "pylda_gamma_device": (_vp, [_vp]),
+    "pylda_mark_device_state": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "pylda_mstep": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, _c_double_p]),
+    "pylda_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "pylda_kernel_time": (ctypes.c_int, [_vp, _c_double_p, _c_int64_p]),
+    "pylda_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+    "pylda_test_special": (ctypes.c_int, [_vp, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p]),
+}
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libpylda_hip.so; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            "pylda_amd: %s is missing - build it with `python -m pylda_amd.build` "
+            "(or __graft_entry__.build()).  pylda_amd has no CPU fallback." % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError => ABI/header mismatch, fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_double_p) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(_c_int32_p) if a is not None else None
+
+
+def _f64(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return a
+
+
+class PyldaError(RuntimeError):
+    def __init__(self, status, message):
+        RuntimeError.__init__(self, "pylda_hip error %d: %s" % (status, message))
+        self.status = status
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    load().pylda_device_count(ctypes.byref(n))
+    return n.value
+
+
+class Context(object):
+    """A model-sized device context: K topics over V word types on one GPU."""
+
+    def __init__(self, number_of_topics, number_of_types, device=0):
+        lib = load()
+        handle = _vp()
+        rc = lib.pylda_create(int(device), int(number_of_topics), int(number_of_types),
+                              ctypes.byref(handle))
+        if rc != 0:
+            raise PyldaError(rc, (lib.pylda_last_error(None) or b"").decode())
+        self._lib = lib
+        self._h = handle
+        self.K = int(number_of_topics)
+        self.V = int(number_of_types)
+        self.device = int(device)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PyldaError(rc, (self._lib.pylda_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pylda_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- model state ----
+    def set_eta(self, eta):
+        self._check(self._lib.pylda_set_eta(self._h, _dp(_f64(eta, (self.K, self.V), "eta"))))
+
+    def get_eta(self):
+        out = np.empty((self.K, self.V), dtype=np.float64)
+        self._check(self._lib.pylda_get_eta(self._h, _dp(out)))
+        return out
+
+    def set_alpha(self, alpha):
+        self._check(self._lib.pylda_set_alpha(self._h, _dp(_f64(alpha, (self.K,), "alpha"))))
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.pylda_set_stream(self._h, _vp(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        self._check(self._lib.pylda_synchronize(self._h))
+
+    def set_option(self, name, value):
+        self._check(self._lib.pylda_set_option(self._h, name.encode(), int(value)))
+
+    # ---- corpus ----
+    def corpus(self, doc_ptr, term_id, term_ct):
+        return Corpus(self, doc_ptr, term_id, term_ct)
+
+    # ---- hot path ----
+    def estep(self, corpus, max_iter=50, tol=1e-6, heldout=False):
+        self._check(self._lib.pylda_estep(self._h, corpus._h, int(max_iter), float(tol),
+                                          1 if heldout else 0))
+
+    def estep_results(self, corpus):
+        ll, wll, nlog = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+        self._check(self._lib.pylda_estep_results(self._h, corpus._h, ctypes.byref(ll),
+                                                  ctypes.byref(wll), ctypes.byref(nlog)))
+        return ll.value, wll.value, nlog.value
+
+    def get_sstats(self):
+        out = np.empty((self.K, self.V), dtype=np.float64)
+        self._check(self._lib.pylda_get_sstats(self._h, _dp(out)))
+        return out
+
+    def get_gamma(self, corpus):
+        out = np.empty((corpus.D, self.K), dtype=np.float64)
+        self._check(self._lib.pylda_get_gamma(self._h, corpus._h, _dp(out)))
+        return out
+
+    def get_doc_values(self, corpus):
+        ll = np.empty(corpus.D, dtype=np.float64)
+        wll = np.empty(corpus.D, dtype=np.float64)
+        iters = np.empty(corpus.D, dtype=np.int32)
+        self._check(self._lib.pylda_get_doc_values(self._h, corpus._h, _dp(ll), _dp(wll), _ip(iters)))
+        return ll, wll, iters
+
+    def estep_host(self, corpus, alpha, eta, max_iter=50, tol=1e-6, heldout=False,
+                   want_doc_values=True):
+        """One-shot form: returns a dict of host arrays."""
+        alpha = _f64(alpha, (self.K,), "alpha")
+        eta = _f64(eta, (self.K, self.V), "eta")
+        gamma = np.empty((corpus.D, self.K), dtype=np.float64)
+        sstats = None if heldout else np.empty((self.K, self.V), dtype=np.float64)
+        ll = np.empty(corpus.D) if want_doc_values else None
+        wll = np.empty(corpus.D) if want_doc_values else None
+        iters = np.empty(corpus.D, dtype=np.int32) if want_doc_values else None
+        scal = np.zeros(2)
+        self._check(self._lib.pylda_estep_host(
+            self._h, corpus._h, _dp(alpha), _dp(eta), int(max_iter), float(tol),
+            1 if heldout else 0, _dp(gamma), _dp(sstats), _dp(ll), _dp(wll), _ip(iters), _dp(scal)))
+        return {"document_log_likelihood": scal[0], "words_log_likelihood": scal[1],
+                "gamma": gamma, "sstats": sstats, "doc_ll": ll, "doc_words_ll": wll, "iters": iters}
+
+    def mstep(self, corpus, beta, want_alpha_ss=True):
+        beta = _f64(beta, (self.V,), "beta")
+        tll = ctypes.c_double(0)
+        ass = np.empty(self.K, dtype=np.float64) if want_alpha_ss else None
+        self._check(self._lib.pylda_mstep(self._h, corpus._h if corpus is not None else None,
+                                          _dp(beta), ctypes.byref(tll), _dp(ass)))
+        return tll.value, ass
+
+    # ---- device-resident interop ----
+    def sstats_device_ptr(self):
+        return int(self._lib.pylda_sstats_device(self._h) or 0)
+
+    def eta_device_ptr(self):
+        return int(self._lib.pylda_eta_device(self._h) or 0)
+
+    def mark_device_state(self, have_eta=-1, have_sstats=-1):
+        self._check(self._lib.pylda_mark_device_state(self._h, int(have_eta), int(have_sstats)))
+
+    # ---- profiling ----
+    def set_profiling(self, enabled):
+        self._check(self._lib.pylda_set_profiling(self._h, 1 if enabled else 0))
+
+    def kernel_time(self):
+        ms, calls = ctypes.c_double(0), ctypes.c_int64(0)
+        self._check(self._lib.pylda_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(calls)))
+        return ms.value, calls.value
+
+    def test_special(self, x):
+        x = _f64(x)
+        dg, lg = np.empty_like(x), np.empty_like(x)
+        self._check(self._lib.pylda_test_special(self._h, x.size, _dp(x), _dp(dg), _dp(lg)))
+        return dg, lg
+
+
+class Corpus(object):
+    """A parsed corpus resident on the device (CSR of distinct term ids/counts)."""
+
+    def __init__(self, ctx, doc_ptr, term_id, term_ct):
+        doc_ptr = np.ascontiguousarray(doc_ptr, dtype=np.int64)
+        term_id = np.ascontiguousarray(term_id, dtype=np.int32)
+        term_ct = np.ascontiguousarray(term_ct, dtype=np.int32)
+        if doc_ptr.ndim != 1 or doc_ptr.size < 1:
+            raise ValueError("doc_ptr must hold D+1 offsets")
+        if term_id.shape != term_ct.shape or term_id.ndim != 1 or term_id.size != doc_ptr[-1]:
+            raise ValueError("term_id/term_ct must be 1-D of length doc_ptr[-1]")
+        handle = _vp()
+        rc = ctx._lib.pylda_corpus_create(
+            ctx._h, doc_ptr.size - 1, doc_ptr.ctypes.data_as(_c_int64_p),
+            term_id.ctypes.data_as(_c_int32_p), term_ct.ctypes.data_as(_c_int32_p),
+            ctypes.byref(handle))
+        ctx._check(rc)
+        self._ctx = ctx
+        self._h = handle
+        self.D = int(doc_ptr.size - 1)
+        self.nnz = int(term_id.size)
+        self.tokens = int(term_ct.sum())
+
+    def gamma_device_ptr(self):
+        return int(self._ctx._lib.pylda_gamma_device(self._h) or 0)
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):
+            self._ctx._lib.pylda_corpus_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,63 @@
+"""Build libpylda_hip.so (gfx950) in-tree with hipcc.
+
+    python -m pylda_amd.build [--force]
+
+The shared library is written to pylda_amd/lib/libpylda_hip.so.  It is
+git-ignored (history stays source-only) but travels to the GPU box with the
+working tree.  hipcc cross-compiles for gfx950 without a GPU present.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libpylda_hip.so")
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+
+
+def _inputs():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(ROOT, "include", "pylda_hip.h"))
+    return deps
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > built for p in _inputs())
+
+
+def build(force=False, verbose=True, extra_flags=()):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+           "-I" + os.path.join(ROOT, "include"), "-o", LIB_PATH + ".tmp"]
+    cmd += list(extra_flags) + sources()
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB_PATH)

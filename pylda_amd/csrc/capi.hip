@@ -1,0 +1,835 @@
+// libpylda_hip.so - host side of the C ABI declared in include/pylda_hip.h.
+//
+// Owns the device-resident model tables and corpora, builds the launch
+// schedule and enqueues the gfx950 kernels.  No CPU fallback exists: every
+// compute entry point requires a HIP device.
+#include "../../include/pylda_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "estep_common.h"
+#include "estep_generic.h"
+#include "estep_logspace.h"
+#include "mstep_kernels.h"
+#include "prepare_kernels.h"
+
+using namespace pylda;
+
+namespace {
+
+std::string g_create_error;
+
+enum Variant : int {
+    kGeneric64 = 0,    // 1 wavefront / document, tile in LDS
+    kGeneric256 = 1,   // 4 wavefronts / document, tile in LDS
+    kGeneric512 = 2,   // 8 wavefronts / document, tile in LDS (up to the whole 160 KiB)
+    kGenericGlobal = 3 // tile larger than LDS: rows re-read from the table
+};
+
+struct Launch {
+    int variant;
+    int64_t first;   // offset into the sorted order
+    int64_t count;   // documents (= workgroups)
+    int n_cap;       // largest distinct-term count in the launch
+    int tile_stride;
+    size_t lds_bytes;
+};
+
+}  // namespace
+
+struct pylda_ctx {
+    int device = 0;
+    int K = 0, V = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    size_t lds_limit = 64 * 1024;
+    int num_cu = 256;
+
+    double* d_eta = nullptr;        // K x V (numpy layout)
+    double* d_elog = nullptr;       // V x K shifted E_log_eta
+    double* d_expElog = nullptr;    // V x K
+    double* d_shift = nullptr;      // V
+    double* d_psi_rowsum = nullptr; // K
+    double* d_topic_lse = nullptr;  // K
+    double* d_alpha = nullptr;      // K
+    double* d_sstats = nullptr;     // V x K
+    double* d_kv_scratch = nullptr; // K x V (export transposes)
+    double* d_beta = nullptr;       // V
+    double* d_small = nullptr;      // scalars + K-vectors scratch
+    double* d_partial = nullptr;    // alpha-ss partials
+    int32_t* d_flag_count = nullptr;
+
+    std::vector<double> h_alpha;
+    bool have_eta = false, have_alpha = false, have_sstats = false;
+    int force_logspace = 0;
+    int force_variant = -1;
+    int plan_epoch = 0;
+
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    std::vector<hipEvent_t> event_pool;
+    double doc_kernel_ms = 0.0;
+    int64_t estep_calls = 0;
+
+    std::string err;
+};
+
+struct pylda_corpus {
+    pylda_ctx* ctx = nullptr;
+    int64_t D = 0, nnz = 0, tokens = 0;
+    int32_t max_terms = 0;
+    int64_t* d_doc_ptr = nullptr;
+    int32_t* d_term_id = nullptr;
+    int32_t* d_term_ct = nullptr;
+    int32_t* d_order = nullptr;
+    double* d_gamma = nullptr;
+    double* d_doc_ll = nullptr;
+    double* d_doc_wll = nullptr;
+    int32_t* d_iters = nullptr;
+    int32_t* d_status = nullptr;
+    int32_t* d_flag_list = nullptr;
+    double* d_scalars = nullptr;   // [0] doc ll, [1] words ll
+    std::vector<int32_t> h_terms_sorted;  // distinct-term counts in schedule order
+    std::vector<Launch> plan;
+    int plan_epoch = 0;
+    bool estep_done = false;
+    int last_heldout = 0;
+};
+
+namespace {
+
+int fail(pylda_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,  \
+                        __LINE__);                                                      \
+    } while (0)
+
+template <typename T>
+int dev_alloc(pylda_ctx* ctx, T** p, size_t n)
+{
+    *p = nullptr;
+    if (n == 0) n = 1;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+    return PYLDA_OK;
+}
+
+template <typename T>
+void dev_free(T*& p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+int tile_stride_for(int K) { return K | 1; }   // odd => conflict-free ds_read_b64 along words
+
+// Decide the kernel variant for a document with n distinct terms.
+int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
+{
+    const int K = ctx->K, stride = tile_stride_for(K);
+    const size_t l64 = generic_lds_layout(K, n, stride, 64, false).total;
+    const size_t l256 = generic_lds_layout(K, n, stride, 256, false).total;
+    const size_t l512 = generic_lds_layout(K, n, stride, 512, false).total;
+    int v;
+    if (ctx->force_variant >= 0) v = ctx->force_variant;
+    else if (l64 <= 20 * 1024) v = kGeneric64;
+    else if (l256 <= 64 * 1024) v = kGeneric256;
+    else if (l512 <= ctx->lds_limit) v = kGeneric512;
+    else v = kGenericGlobal;
+    // a forced LDS variant that does not fit degrades to the global-tile kernel
+    const size_t need = v == kGeneric64 ? l64 : v == kGeneric256 ? l256 : l512;
+    if (v != kGenericGlobal && need > ctx->lds_limit) v = kGenericGlobal;
+    switch (v) {
+    case kGeneric64: *lds_bytes = l64; break;
+    case kGeneric256: *lds_bytes = l256; break;
+    case kGeneric512: *lds_bytes = l512; break;
+    default: *lds_bytes = generic_lds_layout(K, n, stride, 256, true).total; break;
+    }
+    return v;
+}
+
+void build_plan(pylda_corpus* c)
+{
+    pylda_ctx* ctx = c->ctx;
+    c->plan.clear();
+    c->plan_epoch = ctx->plan_epoch;
+    const int64_t D = c->D;
+    int64_t i = 0;
+    while (i < D) {
+        // documents are sorted by distinct-term count, descending: a launch is a
+        // maximal run with the same variant whose LDS request (sized for its first,
+        // largest document) is not more than ~25 % above what its last needs.
+        size_t lds_first;
+        const int v = choose_variant(ctx, c->h_terms_sorted[i], &lds_first);
+        int64_t j = i + 1;
+        while (j < D) {
+            size_t lds_j;
+            const int vj = choose_variant(ctx, c->h_terms_sorted[j], &lds_j);
+            if (vj != v) break;
+            if (v != kGenericGlobal && lds_first > 4096 && lds_j * 5 < lds_first * 4 &&
+                (j - i) >= 4 * (int64_t)ctx->num_cu)
+                break;
+            ++j;
+        }
+        Launch L;
+        L.variant = v;
+        L.first = i;
+        L.count = j - i;
+        L.n_cap = std::max(1, c->h_terms_sorted[i]);
+        L.tile_stride = tile_stride_for(ctx->K);
+        L.lds_bytes = lds_first;
+        c->plan.push_back(L);
+        i = j;
+    }
+}
+
+template <int NT, bool TG>
+int launch_generic(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    auto kern = estep_generic_kernel<NT, TG>;
+    if (L.lds_bytes > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)L.lds_bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(NT), L.lds_bytes, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+int enqueue_prepare(pylda_ctx* ctx, bool heldout)
+{
+    const int K = ctx->K, V = ctx->V;
+    hipLaunchKernelGGL(eta_rowsum_psi_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_eta, K, V,
+                       ctx->d_psi_rowsum);
+    hipLaunchKernelGGL(elog_transpose_kernel, dim3((V + 31) / 32, (K + 31) / 32), dim3(256), 0,
+                       ctx->stream, ctx->d_eta, ctx->d_psi_rowsum, K, V, ctx->d_elog);
+    hipLaunchKernelGGL(row_shift_exp_kernel, dim3((V + 3) / 4), dim3(256), 0, ctx->stream,
+                       ctx->d_elog, K, V, ctx->d_expElog, ctx->d_shift);
+    if (heldout)
+        hipLaunchKernelGGL(topic_lse_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_elog,
+                           ctx->d_shift, K, V, ctx->d_topic_lse);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+hipEvent_t take_event(pylda_ctx* ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void drain_events(pylda_ctx* ctx)
+{
+    for (auto& pr : ctx->pending_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) == hipSuccess &&
+            hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
+            ctx->doc_kernel_ms += ms;
+        ctx->event_pool.push_back(pr.first);
+        ctx->event_pool.push_back(pr.second);
+    }
+    ctx->pending_events.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pylda_version(void) { return "pylda_hip 0.1 (gfx950)"; }
+
+int pylda_device_count(int* count)
+{
+    if (!count) return PYLDA_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return PYLDA_OK;
+}
+
+const char* pylda_last_error(const pylda_ctx* ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int pylda_create(int device, int K, int V, pylda_ctx** out)
+{
+    if (!out) return fail(nullptr, PYLDA_ERR_INVALID, "pylda_create: out is NULL");
+    *out = nullptr;
+    if (K < 1 || V < 1) return fail(nullptr, PYLDA_ERR_INVALID, "pylda_create: K=%d V=%d", K, V);
+    if ((int64_t)K * V > ((int64_t)1 << 40))
+        return fail(nullptr, PYLDA_ERR_INVALID, "pylda_create: K*V too large");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, PYLDA_ERR_HIP,
+                    "pylda_create: no HIP device visible; this library has no CPU fallback");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, PYLDA_ERR_INVALID, "pylda_create: device %d of %d", device, ndev);
+    pylda_ctx* ctx = new (std::nothrow) pylda_ctx;
+    if (!ctx) return fail(nullptr, PYLDA_ERR_OOM, "pylda_create: host allocation failed");
+    ctx->device = device;
+    ctx->K = K;
+    ctx->V = V;
+    auto bail = [&](int code) {
+        g_create_error = ctx->err;
+        pylda_destroy(ctx);
+        return code;
+    };
+#define CREATE_TRY(expr)                     \
+    do {                                     \
+        int rc_ = (expr);                    \
+        if (rc_ != PYLDA_OK) return bail(rc_); \
+    } while (0)
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return (int)PYLDA_OK;
+        return fail(ctx, e == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, "%s: %s", what,
+                    hipGetErrorString(e));
+    };
+    CREATE_TRY(hip_ok(hipSetDevice(device), "hipSetDevice"));
+    hipDeviceProp_t prop;
+    CREATE_TRY(hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties"));
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    size_t lds = prop.maxSharedMemoryPerMultiProcessor;
+    if (lds < 64 * 1024) lds = 64 * 1024;
+    if (lds > 160 * 1024) lds = 160 * 1024;
+    ctx->lds_limit = lds;
+    CREATE_TRY(hip_ok(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking),
+                      "hipStreamCreate"));
+    ctx->stream = ctx->own_stream;
+    const size_t kv = (size_t)K * V;
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_eta, kv));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_elog, kv));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_expElog, kv));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_sstats, kv));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_kv_scratch, kv));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_shift, (size_t)V));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_beta, (size_t)V));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_psi_rowsum, (size_t)K));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_topic_lse, (size_t)K));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_alpha, (size_t)K));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_small, (size_t)(4 * K + 16)));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_partial, (size_t)1024 * K));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_flag_count, (size_t)1));
+    CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_sstats, 0, kv * sizeof(double), ctx->stream),
+                      "hipMemsetAsync"));
+#undef CREATE_TRY
+    *out = ctx;
+    return PYLDA_OK;
+}
+
+void pylda_destroy(pylda_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    drain_events(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    dev_free(ctx->d_eta); dev_free(ctx->d_elog); dev_free(ctx->d_expElog); dev_free(ctx->d_sstats);
+    dev_free(ctx->d_kv_scratch); dev_free(ctx->d_shift); dev_free(ctx->d_beta);
+    dev_free(ctx->d_psi_rowsum); dev_free(ctx->d_topic_lse); dev_free(ctx->d_alpha);
+    dev_free(ctx->d_small); dev_free(ctx->d_partial); dev_free(ctx->d_flag_count);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int pylda_set_stream(pylda_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return PYLDA_OK;
+}
+
+int pylda_synchronize(pylda_ctx* ctx)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PYLDA_OK;
+}
+
+int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
+{
+    if (!ctx || !name) return PYLDA_ERR_INVALID;
+    if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
+    else if (!strcmp(name, "force_variant")) {
+        if (value < -1 || value > kGenericGlobal)
+            return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
+        ctx->force_variant = (int)value;
+        ctx->plan_epoch += 1;
+    } else
+        return fail(ctx, PYLDA_ERR_INVALID, "unknown option '%s'", name);
+    return PYLDA_OK;
+}
+
+int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const int32_t* term_id,
+                        const int32_t* term_ct, pylda_corpus** out)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!out) return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: out is NULL");
+    *out = nullptr;
+    if (D < 0 || D > INT32_MAX || !doc_ptr)
+        return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: D=%lld", (long long)D);
+    if (doc_ptr[0] != 0) return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: doc_ptr[0] != 0");
+    int64_t max_terms = 0;
+    for (int64_t d = 0; d < D; ++d) {
+        const int64_t n = doc_ptr[d + 1] - doc_ptr[d];
+        if (n < 0) return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: doc_ptr not monotone at %lld", (long long)d);
+        max_terms = std::max(max_terms, n);
+    }
+    const int64_t nnz = doc_ptr[D];
+    if (max_terms > (1 << 24))
+        return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: a document has %lld distinct terms", (long long)max_terms);
+    if (nnz > 0 && (!term_id || !term_ct))
+        return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: NULL term arrays");
+    int64_t tokens = 0;
+    for (int64_t i = 0; i < nnz; ++i) {
+        if (term_id[i] < 0 || term_id[i] >= ctx->V)
+            return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: term id %d at %lld outside [0,%d)",
+                        term_id[i], (long long)i, ctx->V);
+        if (term_ct[i] < 1)
+            return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: count %d at %lld", term_ct[i], (long long)i);
+        tokens += term_ct[i];
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pylda_corpus* c = new (std::nothrow) pylda_corpus;
+    if (!c) return fail(ctx, PYLDA_ERR_OOM, "corpus_create: host allocation failed");
+    c->ctx = ctx;
+    c->D = D;
+    c->nnz = nnz;
+    c->tokens = tokens;
+    c->max_terms = (int32_t)max_terms;
+
+    // schedule: longest documents first (stable => deterministic)
+    std::vector<int32_t> order((size_t)D);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return doc_ptr[a + 1] - doc_ptr[a] > doc_ptr[b + 1] - doc_ptr[b];
+    });
+    c->h_terms_sorted.resize((size_t)D);
+    for (int64_t i = 0; i < D; ++i)
+        c->h_terms_sorted[i] = (int32_t)(doc_ptr[order[i] + 1] - doc_ptr[order[i]]);
+    build_plan(c);
+
+    const int K = ctx->K;
+    int rc = PYLDA_OK;
+    auto A = [&](int r) { if (rc == PYLDA_OK) rc = r; };
+    A(dev_alloc(ctx, &c->d_doc_ptr, (size_t)D + 1));
+    A(dev_alloc(ctx, &c->d_term_id, (size_t)nnz));
+    A(dev_alloc(ctx, &c->d_term_ct, (size_t)nnz));
+    A(dev_alloc(ctx, &c->d_order, (size_t)D));
+    A(dev_alloc(ctx, &c->d_gamma, (size_t)D * K));
+    A(dev_alloc(ctx, &c->d_doc_ll, (size_t)D));
+    A(dev_alloc(ctx, &c->d_doc_wll, (size_t)D));
+    A(dev_alloc(ctx, &c->d_iters, (size_t)D));
+    A(dev_alloc(ctx, &c->d_status, (size_t)D));
+    A(dev_alloc(ctx, &c->d_flag_list, (size_t)D));
+    A(dev_alloc(ctx, &c->d_scalars, (size_t)4));
+    if (rc != PYLDA_OK) {
+        pylda_corpus_destroy(c);
+        return rc;
+    }
+    auto H2D = [&](void* dst, const void* src, size_t bytes) {
+        if (rc == PYLDA_OK && bytes)
+            if (hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
+                rc = fail(ctx, PYLDA_ERR_HIP, "corpus_create: H2D copy failed");
+    };
+    H2D(c->d_doc_ptr, doc_ptr, ((size_t)D + 1) * sizeof(int64_t));
+    H2D(c->d_term_id, term_id, (size_t)nnz * sizeof(int32_t));
+    H2D(c->d_term_ct, term_ct, (size_t)nnz * sizeof(int32_t));
+    H2D(c->d_order, order.data(), (size_t)D * sizeof(int32_t));
+    if (rc != PYLDA_OK) {
+        pylda_corpus_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return PYLDA_OK;
+}
+
+void pylda_corpus_destroy(pylda_corpus* c)
+{
+    if (!c) return;
+    if (c->ctx) {
+        (void)hipSetDevice(c->ctx->device);
+        (void)hipStreamSynchronize(c->ctx->stream);
+    }
+    dev_free(c->d_doc_ptr); dev_free(c->d_term_id); dev_free(c->d_term_ct); dev_free(c->d_order);
+    dev_free(c->d_gamma); dev_free(c->d_doc_ll); dev_free(c->d_doc_wll); dev_free(c->d_iters);
+    dev_free(c->d_status); dev_free(c->d_flag_list); dev_free(c->d_scalars);
+    delete c;
+}
+
+int pylda_corpus_info(const pylda_corpus* c, int64_t* D, int64_t* nnz, int64_t* tokens,
+                      int32_t* max_terms)
+{
+    if (!c) return PYLDA_ERR_INVALID;
+    if (D) *D = c->D;
+    if (nnz) *nnz = c->nnz;
+    if (tokens) *tokens = c->tokens;
+    if (max_terms) *max_terms = c->max_terms;
+    return PYLDA_OK;
+}
+
+int pylda_set_eta(pylda_ctx* ctx, const double* eta_kv)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!eta_kv) return fail(ctx, PYLDA_ERR_INVALID, "set_eta: NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eta, eta_kv, (size_t)ctx->K * ctx->V * sizeof(double),
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host buffer is not retained
+    ctx->have_eta = true;
+    return PYLDA_OK;
+}
+
+int pylda_get_eta(pylda_ctx* ctx, double* eta_kv)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!eta_kv) return fail(ctx, PYLDA_ERR_INVALID, "get_eta: NULL");
+    if (!ctx->have_eta) return fail(ctx, PYLDA_ERR_STATE, "get_eta: eta was never set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(eta_kv, ctx->d_eta, (size_t)ctx->K * ctx->V * sizeof(double),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PYLDA_OK;
+}
+
+int pylda_set_alpha(pylda_ctx* ctx, const double* alpha_k)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!alpha_k) return fail(ctx, PYLDA_ERR_INVALID, "set_alpha: NULL");
+    for (int k = 0; k < ctx->K; ++k)
+        if (!(alpha_k[k] > 0.0) || !std::isfinite(alpha_k[k]))
+            return fail(ctx, PYLDA_ERR_INVALID, "set_alpha: alpha[%d]=%g is not positive", k, alpha_k[k]);
+    ctx->h_alpha.assign(alpha_k, alpha_k + ctx->K);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_alpha, ctx->h_alpha.data(), (size_t)ctx->K * sizeof(double),
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_alpha = true;
+    return PYLDA_OK;
+}
+
+int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int heldout)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!c || c->ctx != ctx) return fail(ctx, PYLDA_ERR_INVALID, "estep: corpus does not belong to this context");
+    if (max_iter < 1) return fail(ctx, PYLDA_ERR_INVALID, "estep: local_parameter_iteration=%d (must be >= 1)", max_iter);
+    if (!(tol >= 0.0) && !(tol < 0.0)) return fail(ctx, PYLDA_ERR_INVALID, "estep: threshold is NaN");
+    if (!ctx->have_eta || !ctx->have_alpha)
+        return fail(ctx, PYLDA_ERR_STATE, "estep: set_eta and set_alpha must be called first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int K = ctx->K, V = ctx->V;
+    heldout = heldout ? 1 : 0;
+
+    int rc = enqueue_prepare(ctx, heldout != 0);                      // :152-155
+    if (rc != PYLDA_OK) return rc;
+    if (!heldout)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_sstats, 0, (size_t)K * V * sizeof(double), ctx->stream));  // :147
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_flag_count, 0, sizeof(int32_t), ctx->stream));
+
+    EstepParams p;
+    p.K = K;
+    p.V = V;
+    p.expElog = ctx->d_expElog;
+    p.shift = ctx->d_shift;
+    p.topic_lse = ctx->d_topic_lse;
+    p.alpha = ctx->d_alpha;
+    double asum = 0.0, alg = 0.0;
+    for (double a : ctx->h_alpha) {
+        asum += a;
+        alg += std::lgamma(a);
+    }
+    p.alpha_term = std::lgamma(asum) - alg;                           // :195
+    p.doc_ptr = c->d_doc_ptr;
+    p.term_id = c->d_term_id;
+    p.term_ct = c->d_term_ct;
+    p.max_iter = max_iter;
+    p.tol = tol;
+    p.heldout = heldout;
+    p.gamma = c->d_gamma;
+    p.doc_ll = c->d_doc_ll;
+    p.doc_words_ll = c->d_doc_wll;
+    p.iters = c->d_iters;
+    p.sstats = ctx->d_sstats;
+    p.status = c->d_status;
+
+    if (c->plan_epoch != ctx->plan_epoch) build_plan(c);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ctx->profiling) {
+        ev0 = take_event(ctx);
+        ev1 = take_event(ctx);
+        HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
+    }
+    if (ctx->force_logspace) {
+        // test hook: mark every document for the log-space kernel
+        std::vector<int32_t> ones((size_t)c->D, 1);
+        HIP_TRY(ctx, hipMemcpyAsync(c->d_status, ones.data(), (size_t)c->D * sizeof(int32_t),
+                                    hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        for (const Launch& L : c->plan) {
+            p.order = c->d_order + L.first;
+            p.n_cap = L.n_cap;
+            p.tile_stride = L.tile_stride;
+            switch (L.variant) {
+            case kGeneric64: rc = launch_generic<64, false>(ctx, p, L); break;
+            case kGeneric256: rc = launch_generic<256, false>(ctx, p, L); break;
+            case kGeneric512: rc = launch_generic<512, false>(ctx, p, L); break;
+            default: rc = launch_generic<256, true>(ctx, p, L); break;
+            }
+            if (rc != PYLDA_OK) return rc;
+        }
+    }
+    if (ctx->profiling) {
+        HIP_TRY(ctx, hipEventRecord(ev1, ctx->stream));
+        ctx->pending_events.emplace_back(ev0, ev1);
+        ctx->estep_calls += 1;
+    }
+
+    // safety net: documents the linear-space kernels flagged are redone in log space
+    if (c->D > 0) {
+        hipLaunchKernelGGL(flagged_collect_kernel, dim3((unsigned)((c->D + 255) / 256)), dim3(256), 0,
+                           ctx->stream, c->d_status, c->D, c->d_flag_list, ctx->d_flag_count);
+        p.order = nullptr;
+        const unsigned grid = (unsigned)std::min<int64_t>(c->D, 4 * (int64_t)ctx->num_cu);
+        hipLaunchKernelGGL(estep_logspace_kernel, dim3(grid), dim3(256), logspace_lds_bytes(K),
+                           ctx->stream, p, ctx->d_elog, c->d_flag_list, ctx->d_flag_count);
+    }
+    hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_doc_ll, c->D,
+                       c->d_scalars);
+    hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_doc_wll, c->D,
+                       c->d_scalars + 1);
+    HIP_TRY(ctx, hipGetLastError());
+    c->estep_done = true;
+    c->last_heldout = heldout;
+    if (!heldout) ctx->have_sstats = true;
+    return PYLDA_OK;
+}
+
+int pylda_estep_results(pylda_ctx* ctx, pylda_corpus* c, double* document_log_likelihood,
+                        double* words_log_likelihood, int64_t* logspace_documents)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!c || c->ctx != ctx) return fail(ctx, PYLDA_ERR_INVALID, "estep_results: bad corpus");
+    if (!c->estep_done) return fail(ctx, PYLDA_ERR_STATE, "estep_results: no E-step has run on this corpus");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double sc[2] = {0, 0};
+    int32_t nflag = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(sc, c->d_scalars, sizeof sc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&nflag, ctx->d_flag_count, sizeof nflag, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (document_log_likelihood) *document_log_likelihood = sc[0];
+    if (words_log_likelihood) *words_log_likelihood = sc[1];
+    if (logspace_documents) *logspace_documents = nflag;
+    return PYLDA_OK;
+}
+
+int pylda_get_sstats(pylda_ctx* ctx, double* sstats_kv)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!sstats_kv) return fail(ctx, PYLDA_ERR_INVALID, "get_sstats: NULL");
+    if (!ctx->have_sstats) return fail(ctx, PYLDA_ERR_STATE, "get_sstats: no training-mode E-step has run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int K = ctx->K, V = ctx->V;
+    // device layout is (V, K); hand back numpy's (K, V)
+    hipLaunchKernelGGL(transpose_kernel, dim3((K + 31) / 32, (V + 31) / 32), dim3(256), 0, ctx->stream,
+                       ctx->d_sstats, V, K, ctx->d_kv_scratch);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(sstats_kv, ctx->d_kv_scratch, (size_t)K * V * sizeof(double),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PYLDA_OK;
+}
+
+int pylda_get_gamma(pylda_ctx* ctx, pylda_corpus* c, double* gamma_dk)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!c || c->ctx != ctx || !gamma_dk) return fail(ctx, PYLDA_ERR_INVALID, "get_gamma: bad argument");
+    if (!c->estep_done) return fail(ctx, PYLDA_ERR_STATE, "get_gamma: no E-step has run on this corpus");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(gamma_dk, c->d_gamma, (size_t)c->D * ctx->K * sizeof(double),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PYLDA_OK;
+}
+
+int pylda_get_doc_values(pylda_ctx* ctx, pylda_corpus* c, double* doc_ll, double* doc_words_ll,
+                         int32_t* iters)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!c || c->ctx != ctx) return fail(ctx, PYLDA_ERR_INVALID, "get_doc_values: bad corpus");
+    if (!c->estep_done) return fail(ctx, PYLDA_ERR_STATE, "get_doc_values: no E-step has run on this corpus");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (doc_ll)
+        HIP_TRY(ctx, hipMemcpyAsync(doc_ll, c->d_doc_ll, (size_t)c->D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (doc_words_ll)
+        HIP_TRY(ctx, hipMemcpyAsync(doc_words_ll, c->d_doc_wll, (size_t)c->D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (iters)
+        HIP_TRY(ctx, hipMemcpyAsync(iters, c->d_iters, (size_t)c->D * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PYLDA_OK;
+}
+
+int pylda_estep_host(pylda_ctx* ctx, pylda_corpus* c, const double* alpha_k, const double* eta_kv,
+                     int max_iter, double tol, int heldout, double* gamma_dk, double* sstats_kv,
+                     double* doc_ll, double* doc_words_ll, int32_t* iters, double* scalars_out)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    int rc;
+    if ((rc = pylda_set_alpha(ctx, alpha_k)) != PYLDA_OK) return rc;
+    if ((rc = pylda_set_eta(ctx, eta_kv)) != PYLDA_OK) return rc;
+    if ((rc = pylda_estep(ctx, c, max_iter, tol, heldout)) != PYLDA_OK) return rc;
+    double sc[2];
+    if ((rc = pylda_estep_results(ctx, c, &sc[0], &sc[1], nullptr)) != PYLDA_OK) return rc;
+    if (scalars_out) {
+        scalars_out[0] = sc[0];
+        scalars_out[1] = sc[1];
+    }
+    if (gamma_dk && (rc = pylda_get_gamma(ctx, c, gamma_dk)) != PYLDA_OK) return rc;
+    if (sstats_kv && !heldout && (rc = pylda_get_sstats(ctx, sstats_kv)) != PYLDA_OK) return rc;
+    if (doc_ll || doc_words_ll || iters)
+        if ((rc = pylda_get_doc_values(ctx, c, doc_ll, doc_words_ll, iters)) != PYLDA_OK) return rc;
+    return PYLDA_OK;
+}
+
+void* pylda_sstats_device(pylda_ctx* ctx) { return ctx ? ctx->d_sstats : nullptr; }
+void* pylda_eta_device(pylda_ctx* ctx) { return ctx ? ctx->d_eta : nullptr; }
+void* pylda_gamma_device(pylda_corpus* c) { return c ? c->d_gamma : nullptr; }
+
+int pylda_mark_device_state(pylda_ctx* ctx, int have_eta, int have_sstats)
+{
+    // the caller wrote eta / sstats through the device pointers above
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (have_eta >= 0) ctx->have_eta = have_eta != 0;
+    if (have_sstats >= 0) ctx->have_sstats = have_sstats != 0;
+    return PYLDA_OK;
+}
+
+int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* topic_log_likelihood,
+                double* alpha_ss_k)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!beta_v) return fail(ctx, PYLDA_ERR_INVALID, "mstep: beta is NULL");
+    if (!ctx->have_eta || !ctx->have_sstats)
+        return fail(ctx, PYLDA_ERR_STATE, "mstep: needs eta and the sufficient statistics of a training E-step");
+    if (alpha_ss_k && (!c || c->ctx != ctx || !c->estep_done))
+        return fail(ctx, PYLDA_ERR_STATE, "mstep: alpha statistics need the corpus of the last E-step");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int K = ctx->K, V = ctx->V;
+    double bsum = 0.0, blg = 0.0;
+    for (int v = 0; v < V; ++v) {
+        if (!(beta_v[v] > 0.0)) return fail(ctx, PYLDA_ERR_INVALID, "mstep: beta[%d]=%g", v, beta_v[v]);
+        bsum += beta_v[v];
+        blg += std::lgamma(beta_v[v]);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_beta, beta_v, (size_t)V * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    double* d_per_topic = ctx->d_small;          // K
+    double* d_alpha_ss = ctx->d_small + K;       // K
+    hipLaunchKernelGGL(mstep_topic_ll_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_eta, K, V, d_per_topic);   // :224 (old eta)
+    hipLaunchKernelGGL(mstep_update_eta_kernel, dim3((K + 31) / 32, (V + 31) / 32), dim3(256), 0, ctx->stream,
+                       ctx->d_sstats, ctx->d_beta, K, V, ctx->d_eta);                                               // :226
+    int nblocks = 0;
+    if (alpha_ss_k) {
+        nblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (c->D + 3) / 4));
+        hipLaunchKernelGGL(mstep_alpha_ss_kernel, dim3(nblocks), dim3(256), (size_t)4 * K * sizeof(double),
+                           ctx->stream, c->d_gamma, c->D, K, ctx->d_partial);                                       // :232
+        hipLaunchKernelGGL(column_sum_kernel, dim3((K + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_partial,
+                           nblocks, K, d_alpha_ss);                                                                 // :233
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<double> per_topic((size_t)K);
+    HIP_TRY(ctx, hipMemcpyAsync(per_topic.data(), d_per_topic, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (alpha_ss_k)
+        HIP_TRY(ctx, hipMemcpyAsync(alpha_ss_k, d_alpha_ss, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double ll = K * (std::lgamma(bsum) - blg);                                                                      // :222
+    for (int k = 0; k < K; ++k) ll += per_topic[k];
+    if (topic_log_likelihood) *topic_log_likelihood = ll;
+    return PYLDA_OK;
+}
+
+int pylda_set_profiling(pylda_ctx* ctx, int enabled)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    ctx->profiling = enabled != 0;
+    return PYLDA_OK;
+}
+
+int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, int64_t* estep_calls)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    drain_events(ctx);
+    if (doc_kernel_ms) *doc_kernel_ms = ctx->doc_kernel_ms;
+    if (estep_calls) *estep_calls = ctx->estep_calls;
+    ctx->doc_kernel_ms = 0.0;
+    ctx->estep_calls = 0;
+    return PYLDA_OK;
+}
+
+namespace {
+__global__ void special_test_kernel(const double* x, int64_t n, double* dg, double* lg)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        dg[i] = pylda::digamma(x[i]);
+        lg[i] = pylda::lgamma_pos(x[i]);
+    }
+}
+}  // namespace
+
+int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digamma_out, double* lgamma_out)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (n < 0 || !x || !digamma_out || !lgamma_out) return fail(ctx, PYLDA_ERR_INVALID, "test_special: bad argument");
+    if (n == 0) return PYLDA_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double *dx = nullptr, *dd = nullptr, *dl = nullptr;
+    int rc = dev_alloc(ctx, &dx, (size_t)n);
+    if (rc == PYLDA_OK) rc = dev_alloc(ctx, &dd, (size_t)n);
+    if (rc == PYLDA_OK) rc = dev_alloc(ctx, &dl, (size_t)n);
+    if (rc == PYLDA_OK) {
+        hipError_t e = hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(special_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dx, n, dd, dl);
+            e = hipStreamSynchronize(ctx->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpy(digamma_out, dd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(lgamma_out, dl, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, PYLDA_ERR_HIP, "test_special: %s", hipGetErrorString(e));
+    }
+    dev_free(dx); dev_free(dd); dev_free(dl);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// Shared device helpers and launch parameter blocks for the E-step kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pylda {
+
+constexpr int kWave = 64;   // CDNA4 wavefront width
+
+// Everything one E-step launch needs.  Tables are WORD-MAJOR (V x K): the
+// reference's E_log_eta[:, ids] column gather (variational_bayes.py:177)
+// becomes a gather of contiguous K-double rows, i.e. coalesced HBM reads.
+struct EstepParams {
+    int K;
+    int V;
+    const double* expElog;    // V x K : exp(E_log_eta[k][w] - shift[w])
+    const double* shift;      // V     : max_k E_log_eta[k][w]
+    const double* topic_lse;  // K     : logsumexp_v E_log_eta[k][:]  (held-out only, :155)
+    const double* alpha;      // K
+    double alpha_term;        // lnG(sum alpha) - sum lnG(alpha)      (:195)
+    const int64_t* doc_ptr;   // D+1
+    const int32_t* term_id;   // nnz
+    const int32_t* term_ct;   // nnz
+    const int32_t* order;     // document ids of this launch, longest first
+    int max_iter;             // local_parameter_iteration            (:132)
+    double tol;               // local_parameter_converge_threshold   (:132)
+    int heldout;              // 1: parsed_corpus given               (:133-138)
+    double* gamma;            // D x K out                            (:188,:213)
+    double* doc_ll;           // D out: this document's terms of :195-199
+    double* doc_words_ll;     // D out: this document's term of :204
+    int32_t* iters;           // D out: inner iterations executed
+    double* sstats;           // V x K, += phi * count                (:207)
+    int32_t* status;          // D out: 0 ok, 1 = linear-space normaliser under/overflowed
+    int n_cap;                // max distinct terms of any document in this launch
+    int tile_stride;          // LDS row stride in doubles (odd)
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = kWave / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int m = kWave / 2; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, kWave));
+    return v;
+}
+
+// Deterministic block-wide reductions; every thread gets the result.
+// `scratch` holds NT/64 doubles in LDS.
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* scratch)
+{
+    v = wave_sum(v);
+    if constexpr (NT == kWave) return v;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / kWave; ++w) s += scratch[w];
+    return s;
+}
+
+template <int NT>
+__device__ __forceinline__ double block_max(double v, double* scratch)
+{
+    v = wave_max(v);
+    if constexpr (NT == kWave) return v;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double s = scratch[0];
+#pragma unroll
+    for (int w = 1; w < NT / kWave; ++w) s = fmax(s, scratch[w]);
+    return s;
+}
+
+__device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+}  // namespace pylda

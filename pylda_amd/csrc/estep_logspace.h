@@ -1,0 +1,146 @@
+// Log-space E-step kernel: the reference's formulation, evaluated on the
+// device without the exp-hoisting.  It is the safety net of the hot path:
+// a document whose linear-space normaliser leaves the fp64 range (possible
+// only when some alpha_k has collapsed below ~1e-3, so that
+// exp(psi(gamma_k) - max psi) underflows for the very topic that carries a
+// word) is flagged by the fast kernels and redone here.  It recomputes
+// log phi = E_log_eta[:, w] + psi(gamma) - logsumexp(...) every inner
+// iteration exactly as variational_bayes.py:177-185 does (N_d*K exps per
+// iteration), so it is slow and never on the measured path.
+//
+// One workgroup (4 wavefronts) per document; a wavefront owns a word at a
+// time, lanes stride over topics.
+#pragma once
+#include "estep_common.h"
+#include "special_device.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace pylda {
+
+__host__ __device__ inline size_t logspace_lds_bytes(int K)
+{
+    // psi[K], gam[K], gacc[4][K], scratch[4]
+    return (size_t)(6 * K + 4) * 8 + 64;
+}
+
+__device__ inline void logspace_document(const EstepParams& p, const double* __restrict__ elog_wk,
+                                         int doc, char* smem)
+{
+    constexpr int NT = 256, NW = 4;
+    const int K = p.K;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t lo = p.doc_ptr[doc];
+    const int N = (int)(p.doc_ptr[doc + 1] - lo);
+
+    double* psi = reinterpret_cast<double*>(smem);
+    double* gam = psi + K;
+    double* gacc = gam + K;                 // NW x K
+    double* scratch = gacc + NW * K;
+
+    double local = 0.0;
+    for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
+    const double total = block_sum<NT>(local, scratch);                        // :162
+    for (int k = tid; k < K; k += NT) gam[k] = p.alpha[k] + total / K;          // :165
+    __syncthreads();
+
+    int it = 0;
+    while (it < p.max_iter) {                                                   // :174
+        for (int k = tid; k < K; k += NT) psi[k] = digamma(gam[k]);
+        for (int k = lane; k < K; k += kWave) gacc[wave * K + k] = 0.0;
+        __syncthreads();
+        for (int n = wave; n < N; n += NW) {
+            const double* row = elog_wk + (size_t)p.term_id[lo + n] * K;
+            double m = -INFINITY;
+            for (int k = lane; k < K; k += kWave) m = fmax(m, row[k] + psi[k]);   // :177
+            m = wave_max(m);
+            double s = 0.0;
+            for (int k = lane; k < K; k += kWave) s += exp(row[k] + psi[k] - m);
+            s = wave_sum(s);
+            const double lse = m + log(s);                                      // :182
+            const double lc = log((double)p.term_ct[lo + n]);
+            for (int k = lane; k < K; k += kWave)
+                gacc[wave * K + k] += exp(row[k] + psi[k] - lse + lc);          // :185
+        }
+        __syncthreads();
+        double diff = 0.0;
+        for (int k = tid; k < K; k += NT) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += gacc[w * K + k];
+            const double gnew = p.alpha[k] + s;
+            diff += fabs(gnew - gam[k]);                                        // :187
+            gam[k] = gnew;                                                      // :188
+        }
+        const double change = block_sum<NT>(diff, scratch) / K;
+        ++it;
+        __syncthreads();
+        if (change <= p.tol) break;                                             // :189
+    }
+
+    // final pass: psi[] still holds the digammas of the pre-update gamma.
+    double ent = 0.0, wll = 0.0;
+    for (int n = wave; n < N; n += NW) {
+        const int id = p.term_id[lo + n];
+        const double* row = elog_wk + (size_t)id * K;
+        double m = -INFINITY;
+        for (int k = lane; k < K; k += kWave) m = fmax(m, row[k] + psi[k]);
+        m = wave_max(m);
+        double s = 0.0;
+        for (int k = lane; k < K; k += kWave) s += exp(row[k] + psi[k] - m);
+        s = wave_sum(s);
+        const double lse = m + log(s);
+        const double c = (double)p.term_ct[lo + n];
+        const double lc = log(c);
+        const double sh = p.heldout ? p.shift[id] : 0.0;
+        for (int k = lane; k < K; k += kWave) {
+            const double lp = row[k] + psi[k] - lse;
+            ent = fma(c, exp(lp) * lp, ent);                                    // :199
+            const double pc = exp(lp + lc);
+            if (p.heldout) wll = fma(pc, row[k] + sh - p.topic_lse[k], wll);     // :204
+            else if (pc != 0.0) unsafeAtomicAdd(&p.sstats[(size_t)id * K + k], pc);   // :207
+        }
+    }
+    ent = block_sum<NT>(ent, scratch);
+    wll = block_sum<NT>(wll, scratch);
+    double lg = 0.0, gs = 0.0;
+    for (int k = tid; k < K; k += NT) {
+        const double gk = gam[k];
+        p.gamma[(size_t)doc * K + k] = gk;
+        lg += lgamma_pos(gk);
+        gs += gk;
+    }
+    lg = block_sum<NT>(lg, scratch);
+    gs = block_sum<NT>(gs, scratch);
+    if (tid == 0) {
+        p.doc_ll[doc] = p.alpha_term + lg - lgamma_pos(gs) - ent;              // :195-199
+        p.doc_words_ll[doc] = wll;
+        p.iters[doc] = it;
+        p.status[doc] = 2;        // finished by the log-space kernel
+    }
+}
+
+// Documents flagged (status == 1) by the fast kernels are appended to `list`
+// by flagged_collect_kernel; this kernel grid-strides over that list, so the
+// host never has to read the count back inside the hot path.
+__global__ __launch_bounds__(256) void estep_logspace_kernel(EstepParams p,
+                                                             const double* __restrict__ elog_wk,
+                                                             const int32_t* __restrict__ list,
+                                                             const int32_t* __restrict__ count)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = *count;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        logspace_document(p, elog_wk, list[i], smem);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void flagged_collect_kernel(const int32_t* __restrict__ status,
+                                                              int64_t D, int32_t* __restrict__ list,
+                                                              int32_t* __restrict__ count)
+{
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < D && status[d] == 1) list[atomicAdd(count, 1)] = (int32_t)d;
+}
+
+}  // namespace pylda

@@ -1,0 +1,84 @@
+// Device M-step (variational_bayes.py:218-235) on the resident buffers.
+#pragma once
+#include "estep_common.h"
+#include "special_device.h"
+
+namespace pylda {
+
+// per_topic[k] = sum_v lnG(eta[k][v]) - lnG(sum_v eta[k][v])       (:224)
+__global__ __launch_bounds__(256) void mstep_topic_ll_kernel(const double* __restrict__ eta, int K,
+                                                             int V, double* __restrict__ per_topic)
+{
+    __shared__ double scratch[4];
+    const int k = blockIdx.x;
+    const double* row = eta + (size_t)k * V;
+    double lg = 0.0, s = 0.0;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const double e = row[v];
+        lg += lgamma_pos(e);
+        s += e;
+    }
+    lg = block_sum<256>(lg, scratch);
+    s = block_sum<256>(s, scratch);
+    if (threadIdx.x == 0) per_topic[k] = lg - lgamma_pos(s);
+}
+
+// eta[k][v] = sstats_wk[v][k] + beta[v]                              (:226)
+__global__ __launch_bounds__(256) void mstep_update_eta_kernel(const double* __restrict__ sstats_wk,
+                                                               const double* __restrict__ beta,
+                                                               int K, int V,
+                                                               double* __restrict__ eta)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int k0 = blockIdx.x * 32, v0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int v = v0 + ty + j * 8, k = k0 + tx;
+        if (v < V && k < K) tile[ty + j * 8][tx] = sstats_wk[(size_t)v * K + k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + ty + j * 8, v = v0 + tx;
+        if (v < V && k < K) eta[(size_t)k * V + v] = tile[tx][ty + j * 8] + beta[v];
+    }
+}
+
+// partial[b][k] = sum over this block's documents of psi(gamma_dk) - psi(sum_k gamma_dk)
+// (:232-233).  One wavefront per document at a time; fixed document->block
+// assignment and fixed summation order => bitwise reproducible.
+__global__ __launch_bounds__(256) void mstep_alpha_ss_kernel(const double* __restrict__ gamma,
+                                                             int64_t D, int K,
+                                                             double* __restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* acc = reinterpret_cast<double*>(smem);        // 4 x K
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int k = lane; k < K; k += kWave) acc[wave * K + k] = 0.0;
+    for (int64_t d = (int64_t)blockIdx.x * 4 + wave; d < D; d += (int64_t)gridDim.x * 4) {
+        const double* g = gamma + (size_t)d * K;
+        double s = 0.0;
+        for (int k = lane; k < K; k += kWave) s += g[k];
+        s = wave_sum(s);
+        const double ps = digamma(s);
+        for (int k = lane; k < K; k += kWave) acc[wave * K + k] += digamma(g[k]) - ps;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256)
+        partial[(size_t)blockIdx.x * K + k] = acc[k] + acc[K + k] + acc[2 * K + k] + acc[3 * K + k];
+}
+
+// out[k] = sum_b partial[b][k]
+__global__ __launch_bounds__(256) void column_sum_kernel(const double* __restrict__ partial,
+                                                         int nblocks, int K,
+                                                         double* __restrict__ out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * K + k];
+    out[k] = s;
+}
+
+}  // namespace pylda

@@ -1,0 +1,125 @@
+// Per-outer-iteration table preparation: eta (K x V, numpy layout) ->
+// word-major tables the document kernels gather from.
+//
+// Reference: compute_dirichlet_expectation (inferencer.py:15-18), called at
+// variational_bayes.py:152; the held-out normaliser of :155.
+//
+//   Elog[w][k]    = psi(eta[k][w]) - psi(sum_v eta[k][v]) - shift[w]
+//   shift[w]      = max_k (psi(eta[k][w]) - psi(sum_v eta[k][v]))
+//   expElog[w][k] = exp(Elog[w][k])                   in (0, 1], row max == 1
+//   topic_lse[k]  = logsumexp_v E_log_eta[k][v]       (held-out only)
+//
+// The per-word shift is what keeps the linear-space inner loop inside the
+// fp64 range: E_log_eta spans [-V, 0] (psi(1/V) ~ -V for unseen pairs).
+#pragma once
+#include "estep_common.h"
+#include "special_device.h"
+
+namespace pylda {
+
+// psi_rowsum[k] = psi(sum_v eta[k][v]); one workgroup per topic row.
+__global__ __launch_bounds__(256) void eta_rowsum_psi_kernel(const double* __restrict__ eta,
+                                                             int K, int V,
+                                                             double* __restrict__ psi_rowsum)
+{
+    __shared__ double scratch[4];
+    const int k = blockIdx.x;
+    const double* row = eta + (size_t)k * V;
+    double s = 0.0;
+    for (int v = threadIdx.x; v < V; v += 256) s += row[v];
+    s = block_sum<256>(s, scratch);
+    if (threadIdx.x == 0) psi_rowsum[k] = digamma(s);
+}
+
+// Transposing pass: reads eta coalesced along v, writes the un-shifted
+// E_log_eta word-major, coalesced along k, through a 32x33 LDS tile.
+__global__ __launch_bounds__(256) void elog_transpose_kernel(const double* __restrict__ eta,
+                                                             const double* __restrict__ psi_rowsum,
+                                                             int K, int V,
+                                                             double* __restrict__ elog_wk)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int v0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + ty + j * 8, v = v0 + tx;
+        if (k < K && v < V) tile[ty + j * 8][tx] = digamma(eta[(size_t)k * V + v]) - psi_rowsum[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int v = v0 + ty + j * 8, k = k0 + tx;
+        if (k < K && v < V) elog_wk[(size_t)v * K + k] = tile[tx][ty + j * 8];
+    }
+}
+
+// One wavefront per word row: max-shift and exponentiate in place.
+__global__ __launch_bounds__(256) void row_shift_exp_kernel(double* __restrict__ elog_wk, int K,
+                                                            int V, double* __restrict__ expElog,
+                                                            double* __restrict__ shift)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = blockIdx.x * 4 + threadIdx.x / kWave;
+    if (w >= V) return;
+    double* row = elog_wk + (size_t)w * K;
+    double m = -INFINITY;
+    for (int k = lane; k < K; k += kWave) m = fmax(m, row[k]);
+    m = wave_max(m);
+    for (int k = lane; k < K; k += kWave) {
+        const double e = row[k] - m;
+        row[k] = e;
+        expElog[(size_t)w * K + k] = exp(e);
+    }
+    if (lane == 0) shift[w] = m;
+}
+
+// topic_lse[k] = logsumexp_v (Elog[v][k] + shift[v]); one workgroup per topic.
+__global__ __launch_bounds__(256) void topic_lse_kernel(const double* __restrict__ elog_wk,
+                                                        const double* __restrict__ shift, int K,
+                                                        int V, double* __restrict__ topic_lse)
+{
+    __shared__ double scratch[4];
+    const int k = blockIdx.x;
+    double m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) m = fmax(m, elog_wk[(size_t)v * K + k] + shift[v]);
+    m = block_max<256>(m, scratch);
+    double s = 0.0;
+    for (int v = threadIdx.x; v < V; v += 256) s += exp(elog_wk[(size_t)v * K + k] + shift[v] - m);
+    s = block_sum<256>(s, scratch);
+    if (threadIdx.x == 0) topic_lse[k] = m + log(s);
+}
+
+// K x V <-> V x K transposes of plain fp64 matrices (sstats export, eta import).
+// in: rows x cols row-major; out: cols x rows row-major.
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, int rows,
+                                                        int cols, double* __restrict__ out)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + j * 8, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + j * 8][tx] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + j * 8, r = r0 + tx;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][ty + j * 8];
+    }
+}
+
+// Deterministic sum of a length-n vector into out[0] (single workgroup).
+__global__ __launch_bounds__(1024) void vector_sum_kernel(const double* __restrict__ x, int64_t n,
+                                                          double* __restrict__ out)
+{
+    __shared__ double scratch[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = block_sum<1024>(s, scratch);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+}  // namespace pylda

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by RUNNING THE REFERENCE ITSELF.
+
+Container-only: needs /root/reference (imported through _ref_loader's
+in-memory lib2to3 translation) and its associated-press.tar.gz data archive.
+Outputs are small .npz files of inputs and expected outputs (data, no
+source) written next to this script; they are what travels to the GPU box.
+
+    python tests/golden/make_golden.py            # tiny + AP fixtures (~3 min)
+    python tests/golden/make_golden.py --trace N  # + N-iteration AP K=10 trace
+
+Fixtures
+  tiny_k2.npz        D=3, V=7, K=2 hand-checkable corpus, training + held-out
+  ap_train_k10.npz   AP train split (2000 docs) K=10: state after 2 learning()
+                     iterations, then per-document goldens of the 3rd e_step,
+                     the m_step outputs and the alpha Newton update
+  ap_test_k10.npz    AP test split (221 docs, 30 word types unseen in
+                     training) in held-out mode against the same model
+  ap_trace_k10.npz   per-iteration joint log-likelihood / alpha trace
+  special_fn.npz     scipy psi / gammaln / polygamma samples used to pin the
+                     C oracle's and the HIP kernel's special functions
+"""
+import argparse
+import io
+import os
+import sys
+import tarfile
+import contextlib
+
+import numpy as np
+import scipy.special
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _ref_loader import REFERENCE_ROOT, load_reference  # noqa: E402
+
+
+def read_ap():
+    tf = tarfile.open(os.path.join(REFERENCE_ROOT, "associated-press.tar.gz"))
+    def lines(name):
+        data = tf.extractfile("associated-press/" + name).read().decode("utf-8")
+        return data.splitlines()
+    train = [l.strip().lower() for l in lines("train.dat")]          # launch_train.py:106
+    test = [l.strip().lower() for l in lines("test.dat")]            # launch_test.py:66
+    vocab = [l.strip().lower().split()[0] for l in lines("voc.dat")]  # launch_train.py:114
+    return train, test, vocab
+
+
+def quiet(fn, *a, **kw):
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        return fn(*a, **kw)
+
+
+def csr_of(parsed):
+    ids, cts = parsed
+    ptr = np.zeros(len(ids) + 1, dtype=np.int64)
+    for d, w in enumerate(ids):
+        ptr[d + 1] = ptr[d] + len(w)
+    tid = np.concatenate([np.asarray(w).ravel() for w in ids]).astype(np.int32)
+    tct = np.concatenate([np.asarray(c).ravel() for c in cts]).astype(np.int32)
+    return ptr, tid, tct
+
+
+class PsiCounter:
+    """Counts scipy.special.psi calls to recover the inner-iteration count."""
+
+    def __init__(self):
+        self.real = scipy.special.psi
+        self.calls = 0
+
+    def __enter__(self):
+        def counted(x, *a, **kw):
+            self.calls += 1
+            return self.real(x, *a, **kw)
+        scipy.special.psi = counted
+        return self
+
+    def __exit__(self, *exc):
+        scipy.special.psi = self.real
+
+
+def per_document(model, parsed, heldout):
+    """Per-document goldens via single-document e_step calls."""
+    ids, cts = parsed
+    D, K = len(ids), model._number_of_topics
+    gamma = np.zeros((D, K))
+    val = np.zeros(D)
+    iters = np.zeros(D, dtype=np.int32)
+    saved_corpus, saved_gamma = model._parsed_corpus, model._gamma
+    for d in range(D):
+        one = ([ids[d]], [cts[d]])
+        with PsiCounter() as pc:
+            if heldout:
+                v, g = quiet(model.e_step, one)
+                gamma[d] = g[0]
+            else:
+                model._parsed_corpus = one
+                v, _ = quiet(model.e_step)
+                gamma[d] = model._gamma[0]
+        val[d] = v
+        iters[d] = pc.calls - 2          # 2 psi calls in compute_dirichlet_expectation
+    model._parsed_corpus, model._gamma = saved_corpus, saved_gamma
+    return gamma, val, iters
+
+
+def make_tiny(vb):
+    docs = ["a b b c", "c c d e e e f", "g a a g b"]
+    vocab = ["a", "b", "c", "d", "e", "f", "g"]
+    np.random.seed(7)
+    m = vb.VariationalBayes()
+    quiet(m._initialize, docs, vocab, 2, 0.5, 0.1)
+    words = [m._index_to_type[i] for i in range(len(vocab))]
+    ptr, tid, tct = csr_of(m._parsed_corpus)
+    quiet(m.learning)
+    alpha, eta = m._alpha_alpha.copy(), m._eta.copy()
+    gamma, doc_ll, iters = per_document(m, m._parsed_corpus, heldout=False)
+    np.random.seed(11)
+    ll, sstats = quiet(m.e_step)
+    gamma_corpus = m._gamma.copy()
+    hgamma, hwll, hiters = per_document(m, m._parsed_corpus, heldout=True)
+    np.random.seed(12)
+    wll, hg = quiet(m.e_step, m._parsed_corpus)
+    np.savez_compressed(
+        os.path.join(HERE, "tiny_k2.npz"), words=np.array(words), docs=np.array(docs),
+        doc_ptr=ptr, term_id=tid, term_ct=tct, alpha=alpha, eta=eta,
+        gamma=gamma, doc_ll=doc_ll, iters=iters, corpus_ll=ll, sstats=sstats,
+        gamma_corpus=gamma_corpus, heldout_gamma=hgamma, heldout_words_ll=hwll,
+        heldout_iters=hiters, heldout_corpus_words_ll=wll, heldout_corpus_gamma=hg)
+    print("tiny_k2: corpus_ll=%r words_ll=%r iters=%s" % (ll, wll, iters))
+
+
+def make_ap(vb, trace_iters):
+    train, test, vocab = read_ap()
+    vocab = list(dict.fromkeys(vocab))
+    K = 10
+    np.random.seed(0)
+    m = vb.VariationalBayes()
+    quiet(m._initialize, train, vocab, K, 1.0 / K, 1.0 / len(vocab))  # launch_train.py:119-124,194
+    words = np.array([m._index_to_type[i] for i in range(len(vocab))])
+    ptr, tid, tct = csr_of(m._parsed_corpus)
+    eta0 = m._eta.copy()
+    trace_ll, trace_alpha = [], []
+    for _ in range(2):
+        trace_ll.append(quiet(m.learning))
+        trace_alpha.append(m._alpha_alpha.copy())
+    alpha, eta = m._alpha_alpha.copy(), m._eta.copy()
+    beta = m._alpha_beta.copy()
+
+    gamma, doc_ll, iters = per_document(m, m._parsed_corpus, heldout=False)
+    np.random.seed(100)
+    ll, sstats = quiet(m.e_step)
+    gamma_corpus = m._gamma.copy()
+    topic_ll, alpha_ss = m.m_step(sstats)
+    eta_after = m._eta.copy()
+    quiet(m.optimize_hyperparameters, alpha_ss)
+    alpha_after = m._alpha_alpha.copy()
+    m._counter += 1
+    trace_ll.append(ll + topic_ll)
+    trace_alpha.append(alpha_after.copy())
+    np.savez_compressed(
+        os.path.join(HERE, "ap_train_k10.npz"), words=words, doc_ptr=ptr,
+        term_id=tid.astype(np.int16), term_ct=tct.astype(np.int16), alpha=alpha, eta=eta,
+        beta=beta, gamma=gamma, doc_ll=doc_ll, iters=iters, corpus_ll=ll, sstats=sstats,
+        gamma_corpus=gamma_corpus, topic_ll=topic_ll, alpha_ss=alpha_ss,
+        eta_after=eta_after, alpha_after=alpha_after)
+    print("ap_train_k10: corpus_ll=%r mean iters=%.2f tokens=%d" % (ll, iters.mean(), tct.sum()))
+
+    # held-out split against the model after 3 iterations
+    parsed_test = quiet(m.parse_data, test)
+    tptr, ttid, ttct = csr_of(parsed_test)
+    hgamma, hwll, hiters = per_document(m, parsed_test, heldout=True)
+    np.random.seed(101)
+    wll, hg = quiet(m.e_step, parsed_test)
+    seen = np.zeros(len(vocab), bool)
+    seen[tid] = True
+    np.savez_compressed(
+        os.path.join(HERE, "ap_test_k10.npz"), doc_ptr=tptr,
+        term_id=ttid.astype(np.int16), term_ct=ttct.astype(np.int16),
+        alpha=m._alpha_alpha.copy(), eta=m._eta.copy(), gamma=hgamma, words_ll=hwll,
+        iters=hiters, corpus_words_ll=wll, corpus_gamma=hg,
+        unseen_types=int((~seen[np.unique(ttid)]).sum()))
+    print("ap_test_k10: words_ll=%r unseen types=%d" % (wll, (~seen[np.unique(ttid)]).sum()))
+
+    if trace_iters > 3:
+        for it in range(3, trace_iters):
+            trace_ll.append(quiet(m.learning))
+            trace_alpha.append(m._alpha_alpha.copy())
+            print("trace iteration %d: %r" % (it + 1, trace_ll[-1]), flush=True)
+    wll_end, _ = quiet(m.inference, test)
+    np.savez_compressed(
+        os.path.join(HERE, "ap_trace_k10.npz"), eta0=eta0.astype(np.float64),
+        joint_ll=np.array(trace_ll), alpha=np.array(trace_alpha),
+        heldout_words_ll_end=wll_end, seed=0)
+    print("ap_trace_k10: %d iterations, final held-out words_ll=%r" % (len(trace_ll), wll_end))
+
+
+def make_special():
+    rng = np.random.default_rng(3)
+    x = np.concatenate([
+        10.0 ** rng.uniform(-6, 4, 4000), rng.uniform(0.0, 12.0, 4000) + 1e-9,
+        np.array([1e-5, 1.0 / 6806, 0.1, 0.5, 1.0, 1.4616321449683623, 2.0, 5.999, 6.0,
+                  9.999, 10.0, 10.001, 100.0, 1234.5, 1e6])])
+    np.savez_compressed(os.path.join(HERE, "special_fn.npz"), x=x, psi=scipy.special.psi(x),
+                        gammaln=scipy.special.gammaln(x),
+                        trigamma=scipy.special.polygamma(1, x))
+    print("special_fn: %d samples" % x.size)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trace", type=int, default=3, help="AP K=10 trace length (iterations)")
+    ap.add_argument("--only", default="", help="comma list of: tiny,ap,special")
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    _, vb = load_reference()
+    if not only or "special" in only:
+        make_special()
+    if not only or "tiny" in only:
+        make_tiny(vb)
+    if not only or "ap" in only:
+        make_ap(vb, args.trace)

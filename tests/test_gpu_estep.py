@@ -1,0 +1,233 @@
+"""Parity of the HIP E-step (through the C ABI) with the oracle and with the
+golden vectors produced by the reference itself.  Needs an MI355X.
+
+Tolerances: the bar BASELINE.json states is 1e-5 relative on the per-document
+log-likelihood; fp64 end to end lets these tests hold 1e-9 or better.
+"""
+import numpy as np
+import pytest
+
+from conftest import csr_slice, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 1e-9        # per-document log-likelihood, relative (bar: 1e-5)
+GAMMA_RTOL = 1e-9
+SSTATS_ATOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pylda_amd import _capi
+    _capi.load()
+    assert _capi.device_count() >= 1, "no HIP device visible"
+    return _capi
+
+
+def run(capi, alpha, eta, ptr, tid, tct, heldout=False, max_iter=50, tol=1e-6, options=()):
+    K, V = eta.shape
+    ctx = capi.Context(K, V)
+    for name, value in options:
+        ctx.set_option(name, value)
+    corpus = ctx.corpus(ptr, tid, tct)
+    out = ctx.estep_host(corpus, alpha, eta, max_iter, tol, heldout)
+    out["logspace_docs"] = ctx.estep_results(corpus)[2]
+    corpus.close()
+    ctx.close()
+    return out
+
+
+def check_against(out, ref_gamma, ref_ll, ref_iters, ll_key="doc_ll", min_same=0.995):
+    same = out["iters"] == ref_iters
+    assert np.mean(same) >= min_same, "inner-iteration counts differ on %d documents" % (~same).sum()
+    assert rel_err(out["gamma"][same], ref_gamma[same]) < GAMMA_RTOL
+    assert rel_err(out[ll_key][same], ref_ll[same]) < LL_RTOL
+    # documents that stop one iteration apart sit on the threshold: still within the 1e-5 bar
+    if (~same).any():
+        assert rel_err(out[ll_key][~same], ref_ll[~same]) < 1e-5
+
+
+def test_device_special_functions(capi):
+    g = load_golden("special_fn.npz")
+    ctx = capi.Context(2, 2)
+    dg, lg = ctx.test_special(g["x"])
+    ctx.close()
+    assert np.max(np.abs(dg - g["psi"]) / np.maximum(1.0, np.abs(g["psi"]))) < 5e-15
+    assert np.max(np.abs(lg - g["gammaln"]) / np.maximum(1.0, np.abs(g["gammaln"]))) < 5e-14
+
+
+def test_tiny_training_and_heldout(capi, tiny):
+    t = tiny
+    out = run(capi, t["alpha"], t["eta"], t["doc_ptr"], t["term_id"], t["term_ct"])
+    assert np.array_equal(out["iters"], t["iters"])
+    assert rel_err(out["gamma"], t["gamma"]) < 1e-12
+    assert rel_err(out["doc_ll"], t["doc_ll"]) < 1e-11
+    assert np.max(np.abs(out["sstats"] - t["sstats"])) < 1e-12
+    assert abs(out["document_log_likelihood"] - float(t["corpus_ll"])) < 1e-11
+    held = run(capi, t["alpha"], t["eta"], t["doc_ptr"], t["term_id"], t["term_ct"], heldout=True)
+    assert np.array_equal(held["iters"], t["heldout_iters"])
+    assert rel_err(held["gamma"], t["heldout_gamma"]) < 1e-12
+    assert rel_err(held["doc_words_ll"], t["heldout_words_ll"]) < 1e-11
+    assert held["sstats"] is None
+
+
+def test_ap_train_k10_matches_reference_goldens(capi, ap_train):
+    g = ap_train
+    out = run(capi, g["alpha"], g["eta"], g["doc_ptr"], g["term_id"], g["term_ct"])
+    assert out["logspace_docs"] == 0
+    check_against(out, g["gamma"], g["doc_ll"], g["iters"])
+    assert np.max(np.abs(out["sstats"] - g["sstats"])) < SSTATS_ATOL
+    assert abs(out["sstats"].sum() - g["term_ct"].sum()) < 1e-6          # tokens conserved
+    assert abs(out["document_log_likelihood"] - float(g["corpus_ll"])) < 1e-9 * abs(float(g["corpus_ll"]))
+    # the headline number: worst per-document relative log-likelihood delta
+    worst = rel_err(out["doc_ll"], g["doc_ll"])
+    print("AP K=10 max per-document relative LL delta: %.3e" % worst)
+    assert worst < 1e-5
+
+
+def test_ap_heldout_k10_matches_reference_goldens(capi, ap_test):
+    g = ap_test
+    out = run(capi, g["alpha"], g["eta"], g["doc_ptr"], g["term_id"], g["term_ct"], heldout=True)
+    check_against(out, g["gamma"], g["words_ll"], g["iters"], ll_key="doc_words_ll", min_same=0.99)
+    assert abs(out["words_log_likelihood"] - float(g["corpus_words_ll"])) < 1e-9 * abs(float(g["corpus_words_ll"]))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_every_kernel_variant_agrees(capi, ap_train, variant):
+    g = ap_train
+    docs = list(range(0, 2000, 10))
+    ptr, tid, tct = csr_slice(g["doc_ptr"], g["term_id"], g["term_ct"], docs)
+    out = run(capi, g["alpha"], g["eta"], ptr, tid, tct, options=[("force_variant", variant)])
+    check_against(out, g["gamma"][docs], g["doc_ll"][docs], g["iters"][docs])
+
+
+def test_logspace_safety_net_kernel_matches(capi, ap_train, ap_test):
+    g = ap_train
+    docs = list(range(0, 2000, 20))
+    ptr, tid, tct = csr_slice(g["doc_ptr"], g["term_id"], g["term_ct"], docs)
+    out = run(capi, g["alpha"], g["eta"], ptr, tid, tct, options=[("force_logspace", 1)])
+    assert out["logspace_docs"] == len(docs)
+    check_against(out, g["gamma"][docs], g["doc_ll"][docs], g["iters"][docs])
+    from oracle import c_oracle
+    ref = c_oracle.e_step(g["alpha"], g["eta"], ptr, tid, tct)
+    assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+    h = ap_test
+    held = run(capi, h["alpha"], h["eta"], h["doc_ptr"], h["term_id"], h["term_ct"], heldout=True,
+               options=[("force_logspace", 1)])
+    check_against(held, h["gamma"], h["words_ll"], h["iters"], ll_key="doc_words_ll", min_same=0.99)
+
+
+def test_collapsed_alpha_triggers_safety_net(capi):
+    """alpha_k ~ 1e-4 makes exp(psi(gamma_k) - max psi) underflow for topics that own
+    words: the fast kernel must flag those documents and the log-space kernel finish them."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(5)
+    K, V, D = 4, 40, 12
+    eta = np.full((K, V), 1e-3)
+    for k in range(K):
+        eta[k, k * 10:(k + 1) * 10] = 50.0            # disjoint topics
+    alpha = np.array([1e-4, 1e-4, 1e-4, 5.0])
+    ptr, ids, cts = [0], [], []
+    for d in range(D):
+        k = d % 3                                      # words only from the collapsed topics
+        w = rng.choice(np.arange(k * 10, (k + 1) * 10), size=3, replace=False)
+        ids += list(w)
+        cts += [1, 1, 1]
+        ptr.append(len(ids))
+    ptr, ids, cts = np.array(ptr), np.array(ids, np.int32), np.array(cts, np.int32)
+    ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, max_iter=3)
+    out = run(capi, alpha, eta, ptr, ids, cts, max_iter=3)
+    assert np.all(np.isfinite(out["gamma"])) and np.all(np.isfinite(out["doc_ll"]))
+    assert rel_err(out["gamma"], ref["gamma"]) < 1e-9
+    assert rel_err(out["doc_ll"], ref["doc_ll"]) < 1e-9
+    assert np.max(np.abs(out["sstats"] - ref["sstats"])) < 1e-10
+
+
+def random_corpus(rng, D, V, mean_len, zipf=1.1):
+    p = 1.0 / np.arange(1, V + 1) ** zipf
+    p /= p.sum()
+    ptr, ids, cts = [0], [], []
+    for _ in range(D):
+        n = max(1, rng.poisson(mean_len))
+        w = rng.choice(V, size=n, p=p)
+        u, c = np.unique(w, return_counts=True)
+        ids.append(u)
+        cts.append(c)
+        ptr.append(ptr[-1] + u.size)
+    return np.array(ptr, np.int64), np.concatenate(ids).astype(np.int32), np.concatenate(cts).astype(np.int32)
+
+
+@pytest.mark.parametrize("K,V,D,mean_len", [(128, 2000, 48, 200), (64, 500, 64, 40), (500, 800, 12, 300),
+                                            (3, 50, 100, 5), (256, 3000, 16, 250), (1, 20, 5, 10)])
+def test_random_corpora_against_c_oracle(capi, K, V, D, mean_len):
+    from oracle import c_oracle
+    rng = np.random.default_rng(K * 1000 + V)
+    ptr, ids, cts = random_corpus(rng, D, V, mean_len)
+    eta = rng.gamma(100.0, 0.01, (K, V))
+    eta[:, rng.choice(V, V // 3, replace=False)] = 1.0 / V          # rows that look "unseen"
+    alpha = rng.uniform(0.05, 1.5, K)
+    ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
+    out = run(capi, alpha, eta, ptr, ids, cts)
+    check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
+    assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+    assert abs(out["sstats"].sum() - cts.sum()) < 1e-7 * cts.sum()
+    held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
+    held = run(capi, alpha, eta, ptr, ids, cts, heldout=True)
+    check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"],
+                  ll_key="doc_words_ll", min_same=0.95)
+
+
+def test_edge_cases_empty_ragged_and_limits(capi):
+    from oracle import c_oracle
+    rng = np.random.default_rng(0)
+    K, V = 7, 30
+    eta = rng.gamma(100.0, 0.01, (K, V))
+    alpha = np.full(K, 1.0 / K)
+    # ragged: an empty document, a one-term document, a document using every type
+    ptr = np.array([0, 0, 1, 1 + V, 1 + V + 2], np.int64)
+    ids = np.concatenate([[4], np.arange(V), [0, V - 1]]).astype(np.int32)
+    cts = np.concatenate([[1000], rng.integers(1, 9, V), [1, 1]]).astype(np.int32)
+    ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
+    out = run(capi, alpha, eta, ptr, ids, cts)
+    assert np.array_equal(out["iters"], ref["iters"])
+    assert out["iters"][0] == 1 and abs(out["doc_ll"][0]) < 1e-12      # empty doc: gamma = alpha
+    assert rel_err(out["gamma"], ref["gamma"]) < 1e-11
+    assert np.max(np.abs(out["doc_ll"] - ref["doc_ll"])) < 1e-9
+    assert np.max(np.abs(out["sstats"] - ref["sstats"])) < 1e-9
+    # iteration cap of 1 and a loose threshold
+    for mi, tol in [(1, 1e-6), (50, 1e-1), (7, 0.0)]:
+        ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
+        out = run(capi, alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
+        assert np.array_equal(out["iters"], ref["iters"])
+        assert rel_err(out["gamma"], ref["gamma"]) < 1e-11
+    # zero documents
+    out = run(capi, alpha, eta, np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert out["gamma"].shape == (0, K) and out["document_log_likelihood"] == 0.0
+    assert np.all(out["sstats"] == 0.0)
+
+
+def test_error_reporting(capi):
+    ctx = capi.Context(3, 5)
+    with pytest.raises(capi.PyldaError) as e:
+        ctx.corpus(np.array([0, 2]), np.array([1, 7], np.int32), np.array([1, 1], np.int32))
+    assert e.value.status == -1 and "outside" in str(e.value)
+    with pytest.raises(capi.PyldaError):
+        ctx.corpus(np.array([0, 1]), np.array([1], np.int32), np.array([0], np.int32))     # zero count
+    corpus = ctx.corpus(np.array([0, 1]), np.array([1], np.int32), np.array([2], np.int32))
+    with pytest.raises(capi.PyldaError) as e:
+        ctx.estep(corpus)                                   # eta / alpha never set
+    assert e.value.status == -4
+    with pytest.raises(capi.PyldaError):
+        ctx.set_alpha(np.array([0.1, -1.0, 0.1]))
+    ctx.set_alpha(np.full(3, 0.1))
+    ctx.set_eta(np.ones((3, 5)))
+    with pytest.raises(capi.PyldaError):
+        ctx.estep(corpus, max_iter=0)
+    with pytest.raises(capi.PyldaError) as e:
+        ctx.get_sstats()                                    # before any training E-step
+    assert e.value.status == -4
+    ctx.estep(corpus)
+    assert ctx.get_sstats().shape == (3, 5)
+    with pytest.raises(capi.PyldaError):
+        capi.Context(0, 5)
+    ctx.close()
