@@ -101,6 +101,8 @@ int pylda_estep_results(pylda_ctx* ctx, pylda_corpus* corpus, double* document_l
 
 /* phi_sufficient_statistics (K, V) of the last training-mode E-step (:214). */
 int pylda_get_sstats(pylda_ctx* ctx, double* sstats_kv);
+/* Upload sufficient statistics (K, V) handed to m_step by the caller (:218). */
+int pylda_set_sstats(pylda_ctx* ctx, const double* sstats_kv);
 /* gamma_values (D, K) of the last E-step over `corpus` (:213,:216). */
 int pylda_get_gamma(pylda_ctx* ctx, pylda_corpus* corpus, double* gamma_dk);
 /* Per-document values (any pointer may be NULL): the document's own terms of

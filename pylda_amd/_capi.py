@@ -36,6 +36,7 @@ SIGNATURES = {
     "pylda_estep": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
     "pylda_estep_results": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, _c_int64_p]),
     "pylda_get_sstats": (ctypes.c_int, [_vp, _c_double_p]),
+    "pylda_set_sstats": (ctypes.c_int, [_vp, _c_double_p]),
     "pylda_get_gamma": (ctypes.c_int, [_vp, _vp, _c_double_p]),
     "pylda_get_doc_values": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, _c_int32_p]),
     "pylda_estep_host": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, ctypes.c_int,
@@ -173,6 +174,9 @@ class Context(object):
         out = np.empty((self.K, self.V), dtype=np.float64)
         self._check(self._lib.pylda_get_sstats(self._h, _dp(out)))
         return out
+
+    def set_sstats(self, sstats):
+        self._check(self._lib.pylda_set_sstats(self._h, _dp(_f64(sstats, (self.K, self.V), "sstats"))))
 
     def get_gamma(self, corpus):
         out = np.empty((corpus.D, self.K), dtype=np.float64)

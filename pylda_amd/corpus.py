@@ -1,0 +1,180 @@
+"""Corpus containers for the hot path.
+
+The reference's parsed corpus is a pair of Python lists
+(variational_bayes.py:120-121): word_ids[d] = int array (N_d,), word_cts[d] =
+int array (1, N_d).  The device wants CSR; these helpers convert both ways,
+shard a corpus across ranks, and generate the synthetic LDA corpora that
+BASELINE.json's configs 3 and 4 name.
+"""
+import numpy as np
+
+
+def lists_to_csr(word_ids, word_cts):
+    D = len(word_ids)
+    lengths = np.fromiter((len(w) for w in word_ids), dtype=np.int64, count=D)
+    doc_ptr = np.zeros(D + 1, dtype=np.int64)
+    np.cumsum(lengths, out=doc_ptr[1:])
+    if D and doc_ptr[-1]:
+        term_id = np.concatenate([np.asarray(w).ravel() for w in word_ids]).astype(np.int32)
+        term_ct = np.concatenate([np.asarray(c).ravel() for c in word_cts]).astype(np.int32)
+    else:
+        term_id = np.zeros(0, np.int32)
+        term_ct = np.zeros(0, np.int32)
+    return doc_ptr, term_id, term_ct
+
+
+def csr_to_lists(doc_ptr, term_id, term_ct):
+    ids, cts = [], []
+    for d in range(len(doc_ptr) - 1):
+        lo, hi = int(doc_ptr[d]), int(doc_ptr[d + 1])
+        ids.append(np.asarray(term_id[lo:hi], dtype=np.int64))
+        cts.append(np.asarray(term_ct[lo:hi], dtype=np.int64)[np.newaxis, :])
+    return ids, cts
+
+
+def shard_bounds(doc_ptr, world_size):
+    """Contiguous document ranges balanced by nnz: returns
+    world_size+1 document offsets."""
+    doc_ptr = np.asarray(doc_ptr, dtype=np.int64)
+    D = doc_ptr.size - 1
+    nnz = int(doc_ptr[-1])
+    bounds = [0]
+    for r in range(1, world_size):
+        target = nnz * r / world_size
+        d = int(np.searchsorted(doc_ptr, target, side="left"))
+        bounds.append(min(max(d, bounds[-1]), D))
+    bounds.append(D)
+    return bounds
+
+
+def shard_csr(doc_ptr, term_id, term_ct, world_size, rank):
+    """This rank's slice of the corpus as its own CSR, plus (first_doc, last_doc)."""
+    b = shard_bounds(doc_ptr, world_size)
+    lo, hi = b[rank], b[rank + 1]
+    a, z = int(doc_ptr[lo]), int(doc_ptr[hi])
+    return (np.asarray(doc_ptr[lo:hi + 1], dtype=np.int64) - a, np.asarray(term_id[a:z]),
+            np.asarray(term_ct[a:z]), (lo, hi))
+
+
+def _dirichlet_rows(rng, concentration, rows, cols):
+    """Dirichlet(concentration * 1) rows via normalised gamma draws (numpy's own
+    dirichlet() switches to a slow stick-breaking path for small concentrations)."""
+    g = rng.standard_gamma(concentration, size=(rows, cols))
+    g /= g.sum(axis=1, keepdims=True)
+    return g
+
+
+def synthetic_lda_corpus(num_docs, vocab_size, true_topics=128, mean_len=200, seed=1234,
+                         topic_concentration=0.01, doc_concentration=0.1, chunk=25000):
+    """LDA generative corpus (cfg 3/4): beta*_k ~ Dir(0.01), theta_d ~
+    Dir(0.1), L_d ~ Poisson(mean_len) >= 1, z ~ theta_d, w ~ beta*_z, collapsed to
+    (distinct id, count) per document.  Returns CSR (doc_ptr, term_id, term_ct).
+
+    Seeding is chunk-wise through SeedSequence.spawn so that no process has to
+    materialise more than `chunk` documents of tokens at a time, and a shard
+    [a, b) of a larger corpus can be generated alone (see `first_doc`)."""
+    return synthetic_lda_shard(num_docs, vocab_size, 0, num_docs, true_topics, mean_len, seed,
+                               topic_concentration, doc_concentration, chunk)
+
+
+def synthetic_lda_shard(num_docs, vocab_size, first_doc, last_doc, true_topics=128, mean_len=200,
+                        seed=1234, topic_concentration=0.01, doc_concentration=0.1, chunk=25000):
+    """Documents [first_doc, last_doc) of synthetic_lda_corpus(num_docs, ...):
+    identical to slicing the full corpus, without generating the rest.
+    first_doc / last_doc must be multiples of `chunk` (or num_docs)."""
+    assert first_doc % chunk == 0 and (last_doc % chunk == 0 or last_doc == num_docs)
+    root = np.random.SeedSequence(seed)
+    n_chunks = (num_docs + chunk - 1) // chunk
+    topic_seed, *chunk_seeds = root.spawn(1 + n_chunks)
+    rng = np.random.Generator(np.random.PCG64(topic_seed))
+    beta = _dirichlet_rows(rng, topic_concentration, true_topics, vocab_size)
+    word_cdf = np.cumsum(beta, axis=1)
+    word_cdf /= word_cdf[:, -1:]
+    word_cdf += np.arange(true_topics)[:, None]          # row k lives in [k, k+1]
+    word_cdf = word_cdf.ravel()
+    ptr_parts, id_parts, ct_parts = [np.zeros(1, np.int64)], [], []
+    base = 0
+    for ci in range(first_doc // chunk, (last_doc + chunk - 1) // chunk):
+        start = ci * chunk
+        n = min(chunk, num_docs - start)
+        rng = np.random.Generator(np.random.PCG64(chunk_seeds[ci]))
+        theta = _dirichlet_rows(rng, doc_concentration, n, true_topics)
+        lengths = np.maximum(rng.poisson(mean_len, size=n), 1)
+        doc_of_token = np.repeat(np.arange(n, dtype=np.int64), lengths)
+        topic_cdf = np.cumsum(theta, axis=1)
+        topic_cdf /= topic_cdf[:, -1:]
+        topic_cdf += np.arange(n)[:, None]
+        z = np.searchsorted(topic_cdf.ravel(), rng.random(doc_of_token.size) + doc_of_token,
+                            side="right") - doc_of_token * true_topics
+        np.clip(z, 0, true_topics - 1, out=z)
+        w = np.searchsorted(word_cdf, rng.random(doc_of_token.size) + z, side="right") - z * vocab_size
+        np.clip(w, 0, vocab_size - 1, out=w)
+        uniq, counts = np.unique(doc_of_token * vocab_size + w, return_counts=True)
+        docs = uniq // vocab_size
+        id_parts.append((uniq % vocab_size).astype(np.int32))
+        ct_parts.append(counts.astype(np.int32))
+        per_doc = np.bincount(docs, minlength=n).astype(np.int64)
+        ptr_parts.append(base + np.cumsum(per_doc))
+        base += int(per_doc.sum())
+    return np.concatenate(ptr_parts), np.concatenate(id_parts), np.concatenate(ct_parts)
+
+
+def synthetic_lda_corpus_torch(num_docs, vocab_size, true_topics=128, mean_len=200, seed=1234,
+                               topic_concentration=0.01, doc_concentration=0.1, device="cpu",
+                               chunk=25000, first_chunk=0, shard_chunks=None):
+    """The same generative process as synthetic_lda_corpus, drawn with torch on
+    `device` (on the GPU a 100k-document corpus takes about a second; host RAM
+    is never asked for the token stream).  Streams differ from the numpy
+    generator's: a corpus is identified by (generator, seed, device type).
+
+    Chunks of `chunk` documents are seeded independently (seed, chunk index),
+    so rank r of a sharded run can draw chunks [first_chunk, first_chunk +
+    shard_chunks) of the global corpus without the rest.
+    Returns numpy CSR (doc_ptr int64, term_id int32, term_ct int32)."""
+    import torch
+    dev = torch.device(device)
+    f64 = torch.float64
+
+    def gen(s):
+        g = torch.Generator(device=dev)
+        g.manual_seed(int(s))
+        return g
+
+    def dirichlet_rows(g, conc, rows, cols):
+        x = torch._standard_gamma(torch.full((rows, cols), conc, dtype=f64, device=dev), generator=g)
+        return x / x.sum(dim=1, keepdim=True)
+
+    g0 = gen(seed * 1000003 + 1)
+    beta = dirichlet_rows(g0, topic_concentration, true_topics, vocab_size)
+    word_cdf = torch.cumsum(beta, dim=1)
+    word_cdf = word_cdf / word_cdf[:, -1:]
+    word_cdf = (word_cdf + torch.arange(true_topics, device=dev, dtype=f64)[:, None]).reshape(-1)
+    del beta
+    n_chunks = (num_docs + chunk - 1) // chunk
+    last_chunk = n_chunks if shard_chunks is None else min(n_chunks, first_chunk + shard_chunks)
+    ptr_parts, id_parts, ct_parts = [np.zeros(1, np.int64)], [], []
+    base = 0
+    for ci in range(first_chunk, last_chunk):
+        n = min(chunk, num_docs - ci * chunk)
+        g = gen(seed * 1000003 + 2 + ci)
+        theta = dirichlet_rows(g, doc_concentration, n, true_topics)
+        lengths = torch.poisson(torch.full((n,), float(mean_len), dtype=f64, device=dev),
+                                generator=g).clamp_(min=1).to(torch.int64)
+        doc = torch.repeat_interleave(torch.arange(n, device=dev), lengths)
+        topic_cdf = torch.cumsum(theta, dim=1)
+        topic_cdf = topic_cdf / topic_cdf[:, -1:]
+        topic_cdf = (topic_cdf + torch.arange(n, device=dev, dtype=f64)[:, None]).reshape(-1)
+        u = torch.rand(doc.numel(), dtype=f64, device=dev, generator=g)
+        z = torch.searchsorted(topic_cdf, u + doc.to(f64), right=True) - doc * true_topics
+        z.clamp_(0, true_topics - 1)
+        u = torch.rand(doc.numel(), dtype=f64, device=dev, generator=g)
+        w = torch.searchsorted(word_cdf, u + z.to(f64), right=True) - z * vocab_size
+        w.clamp_(0, vocab_size - 1)
+        uniq, counts = torch.unique(doc * vocab_size + w, return_counts=True)
+        per_doc = torch.bincount(uniq // vocab_size, minlength=n)
+        id_parts.append((uniq % vocab_size).to(torch.int32).cpu().numpy())
+        ct_parts.append(counts.to(torch.int32).cpu().numpy())
+        ptr_parts.append(base + torch.cumsum(per_doc, 0).cpu().numpy())
+        base += int(per_doc.sum())
+    return (np.concatenate(ptr_parts).astype(np.int64), np.concatenate(id_parts),
+            np.concatenate(ct_parts))

@@ -671,6 +671,23 @@ int pylda_get_sstats(pylda_ctx* ctx, double* sstats_kv)
     return PYLDA_OK;
 }
 
+int pylda_set_sstats(pylda_ctx* ctx, const double* sstats_kv)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!sstats_kv) return fail(ctx, PYLDA_ERR_INVALID, "set_sstats: NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int K = ctx->K, V = ctx->V;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_kv_scratch, sstats_kv, (size_t)K * V * sizeof(double),
+                                hipMemcpyHostToDevice, ctx->stream));
+    // numpy's (K, V) -> device layout (V, K)
+    hipLaunchKernelGGL(transpose_kernel, dim3((V + 31) / 32, (K + 31) / 32), dim3(256), 0, ctx->stream,
+                       ctx->d_kv_scratch, K, V, ctx->d_sstats);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_sstats = true;
+    return PYLDA_OK;
+}
+
 int pylda_get_gamma(pylda_ctx* ctx, pylda_corpus* c, double* gamma_dk)
 {
     if (!ctx) return PYLDA_ERR_INVALID;

@@ -1,0 +1,338 @@
+"""VariationalBayes: PyLDA's variational-Bayes LDA engine with the E-step on an
+MI355X.
+
+Host-side mirror of the reference's plugin seam: same class name, method
+names, keyword defaults, return orders and attributes as
+/root/reference/variational_bayes.py:55-356, so that a launch_train-style
+driver is a drop-in.  The arithmetic of the hot path (e_step, :132-216) runs
+in libpylda_hip.so through the C ABI (pylda_amd/_capi.py); there is no CPU
+implementation of it in this package.
+
+Device residency: eta, the sufficient statistics and gamma live on the GPU
+between calls.  `_eta` and `_gamma` are lazy properties: reading them pulls
+the device copy once, assigning them marks the host copy as the newer one
+(it is uploaded at the next E-step).  learning() therefore moves only
+scalars and K-vectors across PCIe per outer iteration, while the public
+e_step()/m_step() keep the reference's host-array contract exactly.
+"""
+import sys
+import time
+
+import numpy
+import scipy.special
+
+from pylda_amd import _capi
+from pylda_amd.corpus import lists_to_csr
+from pylda_amd.inferencer import Inferencer, compute_dirichlet_expectation
+
+
+class VariationalBayes(Inferencer):
+    def __init__(self, hyper_parameter_optimize_interval=1, device=0, process_group=None):
+        Inferencer.__init__(self, hyper_parameter_optimize_interval)
+        self._device = device
+        self._process_group = process_group        # torch.distributed group, or None
+        self._ctx = None
+        self._train_corpus = None
+        self._eta_host = None
+        self._gamma_host = None
+        self._eta_device_newer = False      # device eta is ahead of the host copy
+        self._eta_host_newer = False        # host eta must be uploaded before the next E-step
+        self._gamma_host_stale = False      # device gamma is ahead of the host copy
+        self._gamma_on_device = False       # the training corpus holds the gamma of an E-step
+        self._verbose = True
+
+    # ------------------------------------------------------------------ state
+    @property
+    def _eta(self):
+        if self._eta_device_newer:
+            self._eta_host = self._ctx.get_eta()
+            self._eta_device_newer = False
+        return self._eta_host
+
+    @_eta.setter
+    def _eta(self, value):
+        self._eta_host = value
+        self._eta_device_newer = False
+        self._eta_host_newer = True
+
+    @property
+    def _gamma(self):
+        if self._gamma_host_stale:
+            self._gamma_host = self._ctx.get_gamma(self._train_corpus)
+            self._gamma_host_stale = False
+        return self._gamma_host
+
+    @_gamma.setter
+    def _gamma(self, value):
+        self._gamma_host = value
+        self._gamma_host_stale = False
+        self._gamma_on_device = False
+
+    def __getstate__(self):
+        """Snapshots are pickles of the whole object (launch_train.py:203-204):
+        materialise the host copies, drop the live device handles."""
+        state = dict(self.__dict__)
+        state["_eta_host"] = self._eta
+        state["_gamma_host"] = self._gamma
+        for key in ("_ctx", "_train_corpus", "_process_group"):
+            state[key] = None
+        state["_eta_device_newer"] = state["_gamma_host_stale"] = False
+        state["_gamma_on_device"] = False
+        state["_eta_host_newer"] = True
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def _context(self):
+        if self._ctx is None:
+            self._ctx = _capi.Context(self._number_of_topics, self._number_of_types, self._device)
+            self._eta_host_newer = True
+            if self._process_group is not None:
+                # run on torch's current stream so the RCCL all-reduce issued through
+                # torch.distributed is stream-ordered with the kernels, no host sync
+                from pylda_amd import distributed
+                distributed.bind_to_torch_stream(self._ctx)
+        return self._ctx
+
+    def _training_corpus(self):
+        if self._train_corpus is None:
+            ptr, ids, cts = lists_to_csr(*self._parsed_corpus)
+            self._train_corpus = self._context().corpus(ptr, ids, cts)
+        return self._train_corpus
+
+    def _push_model(self):
+        ctx = self._context()
+        ctx.set_alpha(self._alpha_alpha)
+        if self._eta_host_newer:
+            ctx.set_eta(self._eta_host)
+            self._eta_host_newer = False
+
+    # ------------------------------------------------------------ initialise
+    def _initialize(self, corpus, vocab, number_of_topics, alpha_alpha, alpha_beta):
+        """variational_bayes.py:82-96 (same RNG draw for eta, so a seeded run
+        starts from the reference's own initial state)."""
+        Inferencer._initialize(self, vocab, number_of_topics, alpha_alpha, alpha_beta)
+        self._parsed_corpus = self.parse_data(corpus)
+        self._number_of_documents = len(self._parsed_corpus[0])
+        self._gamma = (numpy.zeros((self._number_of_documents, self._number_of_topics))
+                       + self._alpha_alpha[numpy.newaxis, :]
+                       + 1.0 * self._number_of_types / self._number_of_topics)          # :92
+        self._eta = numpy.random.gamma(100., 1. / 100.,
+                                       (self._number_of_topics, self._number_of_types))  # :95
+        self._ctx = None
+        self._train_corpus = None
+
+    def _initialize_parsed(self, doc_ptr, term_id, term_ct, number_of_types, number_of_topics,
+                           alpha_alpha, alpha_beta, eta=None):
+        """Same state as _initialize for a corpus that is already parsed to CSR
+        (synthetic corpora, shards of a distributed run): no vocabulary, no text."""
+        self._type_to_index = {}
+        self._index_to_type = {}
+        self._number_of_types = int(number_of_types)
+        self._counter = 0
+        self._number_of_topics = int(number_of_topics)
+        self._alpha_alpha = numpy.zeros(self._number_of_topics) + alpha_alpha
+        self._alpha_beta = numpy.zeros(self._number_of_types) + alpha_beta
+        self._parsed_corpus = None
+        self._number_of_documents = len(doc_ptr) - 1
+        self._gamma = None
+        if eta is None:
+            eta = numpy.random.gamma(100., 1. / 100., (self._number_of_topics, self._number_of_types))
+        self._eta = eta
+        self._ctx = None
+        self._train_corpus = self._context().corpus(doc_ptr, term_id, term_ct)
+
+    def parse_data(self, corpus):
+        """Text lines -> ([ids (N_d,)], [counts (1, N_d)]) (variational_bayes.py:98-130):
+        tokens outside the vocabulary are skipped (:108-109), documents left
+        empty are dropped with a warning (:116-118)."""
+        word_ids, word_cts = [], []
+        lookup = self._type_to_index
+        doc_count = 0
+        for document_line in corpus:
+            tally = {}
+            for token in document_line.split():
+                type_id = lookup.get(token)
+                if type_id is not None:
+                    tally[type_id] = tally.get(type_id, 0) + 1
+            if not tally:
+                sys.stderr.write("warning: document collapsed during parsing")
+                continue
+            word_ids.append(numpy.fromiter(tally.keys(), dtype=numpy.int64, count=len(tally)))
+            word_cts.append(numpy.fromiter(tally.values(), dtype=numpy.int64,
+                                           count=len(tally))[numpy.newaxis, :])
+            doc_count += 1
+            if self._verbose and doc_count % 10000 == 0:
+                print("successfully parse %d documents..." % doc_count)
+        if self._verbose:
+            print("successfully parse %d documents..." % (doc_count))
+        return (word_ids, word_cts)
+
+    # ---------------------------------------------------------------- E-step
+    def e_step(self, parsed_corpus=None, local_parameter_iteration=50,
+               local_parameter_converge_threshold=1e-6):
+        """variational_bayes.py:132-216, on the GPU.
+
+        Training mode (parsed_corpus is None): returns (document_log_likelihood,
+        phi_sufficient_statistics (K, V) ndarray) and sets self._gamma.
+        Held-out mode: returns (words_log_likelihood, gamma_values (D, K));
+        self._gamma is left untouched (:212-216).
+        """
+        ctx = self._context()
+        self._push_model()
+        if parsed_corpus is None:
+            corpus = self._training_corpus()
+            ctx.estep(corpus, local_parameter_iteration, local_parameter_converge_threshold, False)
+            document_log_likelihood, _, _ = ctx.estep_results(corpus)
+            self._gamma_host_stale = self._gamma_on_device = True
+            return document_log_likelihood, ctx.get_sstats()
+        word_ids, word_cts = parsed_corpus
+        assert len(word_ids) == len(word_cts)                                   # :140
+        corpus = ctx.corpus(*lists_to_csr(word_ids, word_cts))
+        try:
+            ctx.estep(corpus, local_parameter_iteration, local_parameter_converge_threshold, True)
+            _, words_log_likelihood, _ = ctx.estep_results(corpus)
+            gamma_values = ctx.get_gamma(corpus)
+        finally:
+            corpus.close()
+        return words_log_likelihood, gamma_values
+
+    # ---------------------------------------------------------------- M-step
+    def m_step(self, phi_sufficient_statistics):
+        """variational_bayes.py:218-235 on the device: topic log-likelihood from
+        the pre-update eta, eta <- sstats + beta, alpha sufficient statistics
+        from the gamma of the last training E-step."""
+        ctx = self._context()
+        self._push_model()
+        phi_sufficient_statistics = numpy.asarray(phi_sufficient_statistics, dtype=numpy.float64)
+        assert phi_sufficient_statistics.shape == (self._number_of_topics, self._number_of_types)
+        ctx.set_sstats(phi_sufficient_statistics)
+        corpus = self._training_corpus()
+        if not self._gamma_on_device:
+            raise RuntimeError("m_step needs the gamma of a training e_step() on this object")
+        topic_log_likelihood, alpha_sufficient_statistics = ctx.mstep(corpus, self._alpha_beta)
+        self._eta_device_newer = True
+        self._eta_host_newer = False
+        return topic_log_likelihood, alpha_sufficient_statistics
+
+    # -------------------------------------------------------------- learning
+    def learning(self):
+        """One outer VB iteration (variational_bayes.py:239-261), device-resident:
+        E-step -> [RCCL all-reduce of the sufficient statistics] -> M-step ->
+        alpha Newton update.  Only scalars and K-vectors cross PCIe."""
+        self._counter += 1
+        ctx = self._context()
+        self._push_model()
+        corpus = self._training_corpus()
+
+        clock_e_step = time.time()
+        ctx.estep(corpus, 50, 1e-6, False)
+        group = self._process_group
+        if group is not None:
+            from pylda_amd import distributed
+            distributed.allreduce_sstats(ctx, group)
+        document_log_likelihood, _, _ = ctx.estep_results(corpus)
+        self._gamma_host_stale = self._gamma_on_device = True
+        clock_e_step = time.time() - clock_e_step
+
+        clock_m_step = time.time()
+        topic_log_likelihood, alpha_sufficient_statistics = ctx.mstep(corpus, self._alpha_beta)
+        self._eta_device_newer = True
+        number_of_documents = self._number_of_documents
+        if group is not None:
+            from pylda_amd import distributed
+            document_log_likelihood, number_of_documents, alpha_sufficient_statistics = \
+                distributed.allreduce_small(group, document_log_likelihood,
+                                            self._number_of_documents, alpha_sufficient_statistics)
+        if self._hyper_parameter_optimize_interval > 0 and \
+                self._counter % self._hyper_parameter_optimize_interval == 0:
+            self.optimize_hyperparameters(alpha_sufficient_statistics,
+                                          number_of_documents=number_of_documents)
+        clock_m_step = time.time() - clock_m_step
+
+        joint_log_likelihood = document_log_likelihood + topic_log_likelihood
+        if self._verbose:
+            print("e_step and m_step of iteration %d finished in %d and %d seconds respectively "
+                  "with log likelihood %g" % (self._counter, clock_e_step, clock_m_step,
+                                              joint_log_likelihood))
+        return joint_log_likelihood
+
+    def inference(self, corpus):
+        """variational_bayes.py:263-271."""
+        parsed_corpus = self.parse_data(corpus)
+        words_log_likelihood, corpus_gamma_values = self.e_step(parsed_corpus)
+        return words_log_likelihood, corpus_gamma_values
+
+    # --------------------------------------------------------- alpha update
+    def optimize_hyperparameters(self, alpha_sufficient_statistics, hyper_parameter_iteration=100,
+                                 hyper_parameter_decay_factor=0.9, hyper_parameter_maximum_decay=10,
+                                 hyper_parameter_converge_threshold=1e-6, number_of_documents=None):
+        """Newton update of alpha with a decaying step (variational_bayes.py:277-324).
+
+        K-sized host arithmetic.  Keeps the reference's formula, including its
+        element-wise 1/hessian where Blei's closed form has a sum (:292-295);
+        end-to-end likelihood traces only match with it.
+        """
+        assert alpha_sufficient_statistics.shape == (self._number_of_topics,)
+        docs = self._number_of_documents if number_of_documents is None else number_of_documents
+        psi, trigamma = scipy.special.psi, lambda x: scipy.special.polygamma(1, x)
+        accepted = self._alpha_alpha
+        decay = 0
+        for _ in range(hyper_parameter_iteration):
+            alpha = self._alpha_alpha
+            total = numpy.sum(alpha)
+            gradient = docs * (psi(total) - psi(alpha)) + alpha_sufficient_statistics
+            hessian = -docs * trigamma(alpha)
+            if not numpy.all(numpy.isfinite(gradient)):
+                print("illegal alpha gradient vector", gradient)
+            ratio_sum = numpy.sum(gradient / hessian)
+            inverse_hessian = 1.0 / hessian                      # vector, as in the reference
+            z = docs * trigamma(total)
+            correction = ratio_sum / (1.0 / z + inverse_hessian)
+            while True:
+                step = numpy.power(hyper_parameter_decay_factor, decay) * (gradient - correction) / hessian
+                if numpy.any(alpha <= step):
+                    decay += 1
+                    if decay > hyper_parameter_maximum_decay:
+                        break
+                    continue
+                accepted = alpha - step
+                break
+            mean_change = numpy.mean(abs(accepted - alpha))
+            self._alpha_alpha = accepted
+            if mean_change <= hyper_parameter_converge_threshold:
+                break
+
+    # -------------------------------------------------------------- exports
+    def export_beta(self, exp_beta_path, top_display=-1):
+        """Per-topic word distribution, most probable first (variational_bayes.py:326-341)."""
+        E_log_eta = compute_dirichlet_expectation(self._eta)
+        with open(exp_beta_path, 'w') as output:
+            for topic_index in range(self._number_of_topics):
+                output.write("==========\t%d\t==========\n" % (topic_index))
+                row = E_log_eta[topic_index, :]
+                beta_probability = numpy.exp(row - scipy.special.logsumexp(row))
+                ranked = numpy.argsort(beta_probability)[::-1]
+                if top_display > 0:
+                    ranked = ranked[:top_display]
+                for type_index in ranked:
+                    output.write("%s\t%g\n" % (self._index_to_type[type_index],
+                                               beta_probability[type_index]))
+
+    def export_gamma(self, exp_gamma_path, top_display=-1):
+        """Per-document topic proportions, largest first (variational_bayes.py:343-356)."""
+        gamma = self._gamma
+        exp_gamma = gamma / numpy.sum(gamma, axis=1)[:, numpy.newaxis]
+        with open(exp_gamma_path, 'w') as output:
+            for document_index in range(self._number_of_documents):
+                ranked = numpy.argsort(exp_gamma[document_index, :])[::-1]
+                if top_display > 0:
+                    ranked = ranked[:top_display]
+                output.write("%s\n" % "\t".join(
+                    "%d:%g" % (topic_index, exp_gamma[document_index, topic_index])
+                    for topic_index in ranked))
+
+
+if __name__ == "__main__":
+    print("not implemented...")

@@ -1,0 +1,66 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the sharding + all-reduce
+plumbing.  The per-shard E-step stands in as the oracle (this test checks the
+exchange, not the kernel): sharded E-steps + all-reduce(sum) of the sufficient
+statistics and of (LL, D, alpha statistics) must equal the unsharded run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from oracle import c_oracle, vb_numpy
+    from pylda_amd import corpus as C
+    from pylda_amd import distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ap_train_k10.npz"))
+    ptr, ids, cts = g["doc_ptr"][:401].astype(np.int64), g["term_id"].astype(np.int32), g["term_ct"].astype(np.int32)
+    ids, cts = ids[:ptr[-1]], cts[:ptr[-1]]
+    sp, si, sc, (lo, hi) = C.shard_csr(ptr, ids, cts, world, rank)
+    out = c_oracle.e_step(g["alpha"], g["eta"], sp, si, sc)
+    sstats = out["sstats"].copy()
+    distributed.allreduce_array_(sstats)
+    gamma = out["gamma"]
+    alpha_ss = np.sum(vb_numpy.psi(gamma) - vb_numpy.psi(gamma.sum(axis=1))[:, None], axis=0)
+    ll, D, ass = distributed.allreduce_small(None, out["document_log_likelihood"], hi - lo, alpha_ss)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), sstats=sstats, ll=ll, D=D, alpha_ss=ass, lo=lo, hi=hi)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from oracle import c_oracle, vb_numpy
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ap_train_k10.npz"))
+    ptr = g["doc_ptr"][:401].astype(np.int64)
+    ids, cts = g["term_id"][:ptr[-1]].astype(np.int32), g["term_ct"][:ptr[-1]].astype(np.int32)
+    full = c_oracle.e_step(g["alpha"], g["eta"], ptr, ids, cts)
+    alpha_ss = np.sum(vb_numpy.psi(full["gamma"]) - vb_numpy.psi(full["gamma"].sum(axis=1))[:, None], axis=0)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    assert r0["lo"] == 0 and r0["hi"] == r1["lo"] and r1["hi"] == 400
+    for r in (r0, r1):
+        assert np.max(np.abs(r["sstats"] - full["sstats"])) < 1e-10
+        assert abs(float(r["ll"]) - full["document_log_likelihood"]) < 1e-9 * abs(full["document_log_likelihood"])
+        assert int(r["D"]) == 400
+        assert np.max(np.abs(r["alpha_ss"] - alpha_ss)) < 1e-9
+    assert np.array_equal(r0["sstats"], r1["sstats"])      # every rank holds the identical reduced buffer

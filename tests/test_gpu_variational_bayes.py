@@ -1,0 +1,115 @@
+"""The drop-in class: pylda_amd.variational_bayes.VariationalBayes against the
+reference's own traces and return contracts.  Needs an MI355X."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def documents_from_csr(words, ptr, ids, cts):
+    docs = []
+    for d in range(len(ptr) - 1):
+        toks = []
+        for n in range(int(ptr[d]), int(ptr[d + 1])):
+            toks += [str(words[ids[n]])] * int(cts[n])
+        docs.append(" ".join(toks))
+    return docs
+
+
+@pytest.fixture(scope="module")
+def ap_model(ap_train):
+    from pylda_amd.variational_bayes import VariationalBayes
+    g = ap_train
+    words = [str(w) for w in g["words"]]
+    docs = documents_from_csr(words, g["doc_ptr"], g["term_id"], g["term_ct"])
+    np.random.seed(0)                                   # the seed the goldens were made with
+    m = VariationalBayes()
+    m._verbose = False
+    m._initialize(docs, words, 10, 1.0 / 10, 1.0 / len(words))
+    return m
+
+
+def test_learning_trace_matches_reference(ap_model, ap_train):
+    tr = load_golden("ap_trace_k10.npz")
+    m = ap_model
+    assert m._number_of_documents == 2000 and m._number_of_types == 6806
+    assert np.array_equal(m._eta, tr["eta0"])           # same RNG draw as variational_bayes.py:95
+    n = min(6, len(tr["joint_ll"]))
+    for it in range(n):
+        joint = m.learning()
+        assert abs(joint - tr["joint_ll"][it]) < 1e-8 * abs(tr["joint_ll"][it]), it
+        assert rel_err(m._alpha_alpha, tr["alpha"][it]) < 1e-8, it
+        if it == 1:                                     # state the per-document goldens start from
+            assert rel_err(m._alpha_alpha, ap_train["alpha"]) < 1e-9
+            assert rel_err(m._eta, ap_train["eta"]) < 1e-8
+    assert m._counter == n
+
+
+def test_e_step_m_step_contract(ap_model, ap_train):
+    """Public e_step()/m_step() keep the reference's host-array contract (:212-216, :218-235)."""
+    from pylda_amd.variational_bayes import VariationalBayes
+    g = ap_train
+    m = VariationalBayes()
+    m._verbose = False
+    words = [str(w) for w in g["words"]]
+    np.random.seed(1)
+    m._initialize(documents_from_csr(words, g["doc_ptr"][:301], g["term_id"], g["term_ct"]),
+                  words, 10, 0.1, 1.0 / len(words))
+    m._alpha_alpha = g["alpha"].copy()
+    m._eta = g["eta"].copy()
+    ll, sstats = m.e_step()
+    assert isinstance(sstats, np.ndarray) and sstats.shape == (10, 6806) and sstats.dtype == np.float64
+    assert m._gamma.shape == (300, 10)
+    assert rel_err(m._gamma, g["gamma"][:300]) < 1e-9
+    assert abs(ll - g["doc_ll"][:300].sum()) < 1e-9 * abs(g["doc_ll"][:300].sum())
+    from oracle import vb_numpy
+    topic_ll_ref, alpha_ss_ref, eta_ref = vb_numpy.m_step(g["eta"], m._alpha_beta, sstats, m._gamma)
+    topic_ll, alpha_ss = m.m_step(sstats)
+    assert abs(topic_ll - topic_ll_ref) < 1e-10 * abs(topic_ll_ref)
+    assert rel_err(alpha_ss, alpha_ss_ref) < 1e-10
+    assert rel_err(m._eta, eta_ref) < 1e-13
+    alpha_ref = vb_numpy.optimize_hyperparameters(m._alpha_alpha, alpha_ss_ref, 300)
+    m.optimize_hyperparameters(alpha_ss)
+    assert rel_err(m._alpha_alpha, alpha_ref) < 1e-9
+
+
+def test_inference_and_pickle_round_trip(ap_model, ap_test, tmp_path):
+    g = ap_test
+    m = ap_model
+    path = tmp_path / "model-x"
+    with open(path, "wb") as fh:
+        pickle.dump(m, fh)                               # launch_train.py:203-204
+    with open(path, "rb") as fh:
+        m2 = pickle.load(fh)                             # launch_test.py:92
+    assert m2._ctx is None and np.array_equal(m2._eta, m._eta)
+    m2._verbose = False
+    # held-out documents through the text interface, model state of the goldens
+    m2._alpha_alpha = g["alpha"].copy()
+    m2._eta = g["eta"].copy()
+    words = [m2._index_to_type[i] for i in range(m2._number_of_types)]
+    docs = documents_from_csr(words, g["doc_ptr"], g["term_id"], g["term_ct"])
+    gamma_before = m2._gamma.copy()
+    wll, gamma = m2.inference(docs)
+    assert gamma.shape == (221, 10)
+    assert abs(wll - float(g["corpus_words_ll"])) < 1e-9 * abs(float(g["corpus_words_ll"]))
+    assert rel_err(gamma, g["gamma"]) < 1e-8
+    assert np.array_equal(m2._gamma, gamma_before)       # :212-216: _gamma untouched in held-out mode
+
+
+def test_exports(ap_model, tmp_path):
+    m = ap_model
+    m.export_beta(str(tmp_path / "exp_beta"), top_display=5)
+    lines = open(tmp_path / "exp_beta").read().splitlines()
+    assert lines[0] == "==========\t0\t==========" and len(lines) == 10 * 6
+    word, prob = lines[1].split("\t")
+    assert word in m._type_to_index and 0.0 < float(prob) <= 1.0
+    m.export_gamma(str(tmp_path / "exp_gamma"))
+    rows = open(tmp_path / "exp_gamma").read().splitlines()
+    assert len(rows) == 2000 and len(rows[0].split("\t")) == 10
+    probs = [float(x.split(":")[1]) for x in rows[0].split("\t")]
+    assert probs == sorted(probs, reverse=True) and abs(sum(probs) - 1.0) < 1e-4

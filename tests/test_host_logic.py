@@ -1,0 +1,95 @@
+"""CPU tests of the host-side logic: corpus containers, sharding, parse_data,
+vocabulary order, the synthetic generator, the alpha Newton update."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from pylda_amd import corpus as C
+
+
+def test_lists_csr_round_trip():
+    ids = [np.array([3, 1, 2]), np.array([5]), np.array([0, 4])]
+    cts = [np.array([[1, 2, 3]]), np.array([[9]]), np.array([[1, 1]])]
+    ptr, tid, tct = C.lists_to_csr(ids, cts)
+    assert ptr.tolist() == [0, 3, 4, 6] and tid.dtype == np.int32 and tct.tolist() == [1, 2, 3, 9, 1, 1]
+    ids2, cts2 = C.csr_to_lists(ptr, tid, tct)
+    assert all(np.array_equal(a, b) for a, b in zip(ids, ids2))
+    assert cts2[0].shape == (1, 3)                       # variational_bayes.py:121 layout
+    ptr0, tid0, tct0 = C.lists_to_csr([], [])
+    assert ptr0.tolist() == [0] and tid0.size == 0
+
+
+def test_shard_bounds_balance_nnz_and_cover():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 300, size=1000)
+    ptr = np.concatenate([[0], np.cumsum(lens)])
+    for world in (1, 2, 3, 8):
+        b = C.shard_bounds(ptr, world)
+        assert b[0] == 0 and b[-1] == 1000 and all(x <= y for x, y in zip(b, b[1:]))
+        loads = [ptr[b[r + 1]] - ptr[b[r]] for r in range(world)]
+        assert max(loads) - min(loads) <= 2 * lens.max()
+    ids = np.arange(ptr[-1], dtype=np.int32)
+    cts = np.ones(ptr[-1], np.int32)
+    parts = [C.shard_csr(ptr, ids, cts, 4, r) for r in range(4)]
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), ids)
+    assert all(p[0][0] == 0 and p[0][-1] == p[1].size for p in parts)
+    assert C.shard_bounds(np.array([0]), 4) == [0, 0, 0, 0, 0]          # empty corpus
+
+
+def test_parse_data_matches_reference_rules(tiny):
+    from pylda_amd.variational_bayes import VariationalBayes
+    m = VariationalBayes()
+    m._verbose = False
+    m.parse_vocabulary([str(w) for w in tiny["words"]])
+    docs = [str(d) for d in tiny["docs"]] + ["zzz qqq", ""]           # OOV-only and empty lines are dropped
+    ids, cts = m.parse_data(docs)
+    assert len(ids) == 3
+    ptr, tid, tct = C.lists_to_csr(ids, cts)
+    assert np.array_equal(ptr, tiny["doc_ptr"])
+    for d in range(3):                                                  # same multiset {(id, count)}
+        lo, hi = ptr[d], ptr[d + 1]
+        assert dict(zip(tid[lo:hi], tct[lo:hi])) == dict(zip(tiny["term_id"][lo:hi], tiny["term_ct"][lo:hi]))
+    assert cts[0].shape == (1, len(ids[0])) and ids[0].dtype == np.int64
+
+
+def test_vocabulary_order_is_first_occurrence():
+    from pylda_amd.inferencer import Inferencer
+    inf = Inferencer()
+    inf._initialize(["b", "a", "b", "c"], 3, 0.5, 0.25)
+    assert inf._type_to_index == {"b": 0, "a": 1, "c": 2} and inf._index_to_type[2] == "c"
+    assert inf._number_of_types == 3 and inf._alpha_beta.tolist() == [0.25] * 3
+    assert inf._alpha_alpha.tolist() == [0.5] * 3 and inf._counter == 0
+
+
+def test_optimize_hyperparameters_matches_reference_golden(ap_train):
+    from pylda_amd.variational_bayes import VariationalBayes
+    g = ap_train
+    m = VariationalBayes()
+    m._number_of_topics, m._number_of_documents = 10, 2000
+    m._alpha_alpha = g["alpha"].copy()
+    m.optimize_hyperparameters(g["alpha_ss"])
+    assert rel_err(m._alpha_alpha, g["alpha_after"]) < 1e-12          # includes the vector-c quirk (:292-295)
+
+
+def test_dirichlet_expectation_host_helper():
+    from pylda_amd.inferencer import compute_dirichlet_expectation
+    from oracle import vb_numpy
+    x = np.random.default_rng(1).gamma(2.0, 1.0, (4, 9))
+    assert np.allclose(compute_dirichlet_expectation(x), vb_numpy.compute_dirichlet_expectation(x), atol=1e-14)
+    assert np.allclose(compute_dirichlet_expectation(x[0]), vb_numpy.compute_dirichlet_expectation(x[0]), atol=1e-14)
+
+
+def test_synthetic_generators_small():
+    ptr, ids, cts = C.synthetic_lda_corpus(300, 200, true_topics=5, mean_len=30, seed=3, chunk=100)
+    assert len(ptr) == 301 and ptr[-1] == ids.size == cts.size and cts.min() >= 1
+    assert ids.min() >= 0 and ids.max() < 200
+    for d in (0, 17, 299):                                              # ids unique and sorted within a doc
+        w = ids[ptr[d]:ptr[d + 1]]
+        assert np.all(np.diff(w) > 0)
+    a = C.synthetic_lda_shard(300, 200, 100, 200, true_topics=5, mean_len=30, seed=3, chunk=100)
+    assert np.array_equal(a[1], ids[ptr[100]:ptr[200]])                 # shard == slice of the whole
+    p2, i2, c2 = C.synthetic_lda_corpus_torch(300, 200, 5, 30, seed=3, chunk=100)
+    assert len(p2) == 301 and p2[-1] == i2.size and c2.min() >= 1 and i2.max() < 200
+    p3, i3, c3 = C.synthetic_lda_corpus_torch(300, 200, 5, 30, seed=3, chunk=100, first_chunk=1, shard_chunks=1)
+    assert np.array_equal(i3, i2[p2[100]:p2[200]]) and np.array_equal(c3, c2[p2[100]:p2[200]])
+    assert abs(c2.sum() / 300.0 - 30) < 3                               # mean length as requested
