@@ -119,9 +119,12 @@ int pylda_estep_host(pylda_ctx* ctx, pylda_corpus* corpus, const double* alpha_k
                      int32_t* iters, double* scalars_out);
 
 /* Device-resident views for multi-GPU data parallelism: the sufficient
- * statistics live word-major, (V, K) doubles.  The Python side wraps this
- * pointer (zero-copy) and all-reduces it over RCCL between e_step and
- * m_step; elements = K*V.  Also the gamma buffer of a corpus (D, K). */
+ * statistics live word-major, (V, ldk) doubles with ldk = pylda_table_stride
+ * (K rounded up to 16 / 32 / a multiple of 64; padding columns are zero).
+ * The Python side wraps this pointer (zero-copy) and all-reduces its V*ldk
+ * elements over RCCL between e_step and m_step.  Also the gamma buffer of a
+ * corpus, (D, K). */
+int pylda_table_stride(const pylda_ctx* ctx);
 void* pylda_sstats_device(pylda_ctx* ctx);
 void* pylda_eta_device(pylda_ctx* ctx);      /* (K, V) doubles, numpy layout */
 void* pylda_gamma_device(pylda_corpus* corpus);

@@ -42,6 +42,7 @@ SIGNATURES = {
     "pylda_estep_host": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, ctypes.c_int,
                                         ctypes.c_double, ctypes.c_int, _c_double_p, _c_double_p,
                                         _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
+    "pylda_table_stride": (ctypes.c_int, [_vp]),
     "pylda_sstats_device": (_vp, [_vp]),
     "pylda_eta_device": (_vp, [_vp]),
     "pylda_gamma_device": (_vp, [_vp]),
@@ -216,6 +217,10 @@ class Context(object):
         return tll.value, ass
 
     # ---- device-resident interop ----
+    def sstats_elements(self):
+        """Number of doubles behind sstats_device_ptr(): V * table stride."""
+        return self.V * int(self._lib.pylda_table_stride(self._h))
+
     def sstats_device_ptr(self):
         return int(self._lib.pylda_sstats_device(self._h) or 0)
 

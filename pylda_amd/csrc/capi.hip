@@ -22,6 +22,7 @@
 #include "estep_logspace.h"
 #include "mstep_kernels.h"
 #include "prepare_kernels.h"
+#include "sstats_kernels.h"
 
 using namespace pylda;
 
@@ -50,19 +51,20 @@ struct Launch {
 struct pylda_ctx {
     int device = 0;
     int K = 0, V = 0;
+    int ldk = 0;                    // row stride of the word-major tables
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     size_t lds_limit = 64 * 1024;
     int num_cu = 256;
 
     double* d_eta = nullptr;        // K x V (numpy layout)
-    double* d_elog = nullptr;       // V x K shifted E_log_eta
-    double* d_expElog = nullptr;    // V x K
+    double* d_elog = nullptr;       // V x ldk shifted E_log_eta
+    double* d_expElog = nullptr;    // V x ldk
     double* d_shift = nullptr;      // V
     double* d_psi_rowsum = nullptr; // K
     double* d_topic_lse = nullptr;  // K
     double* d_alpha = nullptr;      // K
-    double* d_sstats = nullptr;     // V x K
+    double* d_sstats = nullptr;     // V x ldk
     double* d_kv_scratch = nullptr; // K x V (export transposes)
     double* d_beta = nullptr;       // V
     double* d_small = nullptr;      // scalars + K-vectors scratch
@@ -99,6 +101,19 @@ struct pylda_corpus {
     int32_t* d_status = nullptr;
     int32_t* d_flag_list = nullptr;
     double* d_scalars = nullptr;   // [0] doc ll, [1] words ll
+    double* d_tfinal = nullptr;    // D x ldk
+    double* d_rfinal = nullptr;    // nnz
+    // postings (CSC) of the corpus for the sufficient-statistics gather pass
+    bool have_postings = false;
+    int32_t* d_post_doc = nullptr; // nnz
+    int32_t* d_post_pos = nullptr; // nnz: position in CSR order
+    int64_t* d_seg_begin = nullptr;
+    int64_t* d_seg_end = nullptr;
+    int64_t* d_word_seg_ptr = nullptr;  // V+1
+    double* d_partial = nullptr;   // nseg x ldk
+    int64_t nseg = 0;
+    std::vector<int64_t> h_doc_ptr;     // kept for the lazy postings build
+    std::vector<int32_t> h_term_id;
     std::vector<int32_t> h_terms_sorted;  // distinct-term counts in schedule order
     std::vector<Launch> plan;
     int plan_epoch = 0;
@@ -225,12 +240,92 @@ int enqueue_prepare(pylda_ctx* ctx, bool heldout)
     hipLaunchKernelGGL(eta_rowsum_psi_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_eta, K, V,
                        ctx->d_psi_rowsum);
     hipLaunchKernelGGL(elog_transpose_kernel, dim3((V + 31) / 32, (K + 31) / 32), dim3(256), 0,
-                       ctx->stream, ctx->d_eta, ctx->d_psi_rowsum, K, V, ctx->d_elog);
+                       ctx->stream, ctx->d_eta, ctx->d_psi_rowsum, K, V, ctx->ldk, ctx->d_elog);
     hipLaunchKernelGGL(row_shift_exp_kernel, dim3((V + 3) / 4), dim3(256), 0, ctx->stream,
-                       ctx->d_elog, K, V, ctx->d_expElog, ctx->d_shift);
+                       ctx->d_elog, K, V, ctx->ldk, ctx->d_expElog, ctx->d_shift);
     if (heldout)
         hipLaunchKernelGGL(topic_lse_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_elog,
-                           ctx->d_shift, K, V, ctx->d_topic_lse);
+                           ctx->d_shift, K, V, ctx->ldk, ctx->d_topic_lse);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+// Postings (CSC) of the corpus, built once, on first training E-step: for every
+// word the (document, CSR position) pairs in document order, cut into segments.
+int build_postings(pylda_corpus* c)
+{
+    if (c->have_postings) return PYLDA_OK;
+    pylda_ctx* ctx = c->ctx;
+    const int V = ctx->V;
+    const int64_t D = c->D, nnz = c->nnz;
+    std::vector<int64_t> col_ptr((size_t)V + 1, 0);
+    for (int64_t i = 0; i < nnz; ++i) col_ptr[(size_t)c->h_term_id[i] + 1] += 1;
+    for (int v = 0; v < V; ++v) col_ptr[v + 1] += col_ptr[v];
+    std::vector<int32_t> post_doc((size_t)nnz), post_pos((size_t)nnz);
+    {
+        std::vector<int64_t> fill(col_ptr.begin(), col_ptr.end() - 1);
+        for (int64_t d = 0; d < D; ++d)
+            for (int64_t i = c->h_doc_ptr[d]; i < c->h_doc_ptr[d + 1]; ++i) {
+                const int64_t at = fill[c->h_term_id[i]]++;
+                post_doc[at] = (int32_t)d;
+                post_pos[at] = (int32_t)i;
+            }
+    }
+    std::vector<int64_t> seg_begin, seg_end, word_seg_ptr((size_t)V + 1, 0);
+    for (int v = 0; v < V; ++v) {
+        for (int64_t b = col_ptr[v]; b < col_ptr[v + 1]; b += kSegment) {
+            seg_begin.push_back(b);
+            seg_end.push_back(std::min<int64_t>(b + kSegment, col_ptr[v + 1]));
+        }
+        word_seg_ptr[v + 1] = (int64_t)seg_begin.size();
+    }
+    c->nseg = (int64_t)seg_begin.size();
+    int rc = PYLDA_OK;
+    auto A = [&](int r) { if (rc == PYLDA_OK) rc = r; };
+    A(dev_alloc(ctx, &c->d_post_doc, (size_t)nnz));
+    A(dev_alloc(ctx, &c->d_post_pos, (size_t)nnz));
+    A(dev_alloc(ctx, &c->d_seg_begin, (size_t)c->nseg));
+    A(dev_alloc(ctx, &c->d_seg_end, (size_t)c->nseg));
+    A(dev_alloc(ctx, &c->d_word_seg_ptr, (size_t)V + 1));
+    A(dev_alloc(ctx, &c->d_partial, (size_t)c->nseg * ctx->ldk));
+    if (rc != PYLDA_OK) return rc;
+    auto H2D = [&](void* dst, const void* src, size_t bytes) {
+        if (rc == PYLDA_OK && bytes && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(ctx, PYLDA_ERR_HIP, "postings: H2D copy failed");
+    };
+    H2D(c->d_post_doc, post_doc.data(), (size_t)nnz * sizeof(int32_t));
+    H2D(c->d_post_pos, post_pos.data(), (size_t)nnz * sizeof(int32_t));
+    H2D(c->d_seg_begin, seg_begin.data(), (size_t)c->nseg * sizeof(int64_t));
+    H2D(c->d_seg_end, seg_end.data(), (size_t)c->nseg * sizeof(int64_t));
+    H2D(c->d_word_seg_ptr, word_seg_ptr.data(), ((size_t)V + 1) * sizeof(int64_t));
+    if (rc != PYLDA_OK) return rc;
+    c->have_postings = true;
+    std::vector<int64_t>().swap(c->h_doc_ptr);
+    std::vector<int32_t>().swap(c->h_term_id);
+    return PYLDA_OK;
+}
+
+int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
+{
+    const int ldk = ctx->ldk;
+    if (c->nseg > 0) {
+        const dim3 grid((unsigned)((c->nseg + 3) / 4), (unsigned)((ldk + 63) / 64));
+        if (ldk == 16)
+            hipLaunchKernelGGL(sstats_gather_kernel<16>, grid, dim3(256), 0, ctx->stream, c->d_seg_begin,
+                               c->d_seg_end, c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal,
+                               c->d_rfinal, ldk, c->d_partial);
+        else if (ldk == 32)
+            hipLaunchKernelGGL(sstats_gather_kernel<32>, grid, dim3(256), 0, ctx->stream, c->d_seg_begin,
+                               c->d_seg_end, c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal,
+                               c->d_rfinal, ldk, c->d_partial);
+        else
+            hipLaunchKernelGGL(sstats_gather_kernel<64>, grid, dim3(256), 0, ctx->stream, c->d_seg_begin,
+                               c->d_seg_end, c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal,
+                               c->d_rfinal, ldk, c->d_partial);
+    }
+    const int64_t total = (int64_t)ctx->V * ldk;
+    hipLaunchKernelGGL(sstats_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       c->d_word_seg_ptr, c->d_partial, ctx->d_expElog, ctx->V, ldk, ctx->d_sstats);
     HIP_TRY(ctx, hipGetLastError());
     return PYLDA_OK;
 }
@@ -298,6 +393,7 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     ctx->device = device;
     ctx->K = K;
     ctx->V = V;
+    ctx->ldk = K <= 16 ? 16 : K <= 32 ? 32 : (K + 63) / 64 * 64;
     auto bail = [&](int code) {
         g_create_error = ctx->err;
         pylda_destroy(ctx);
@@ -324,11 +420,11 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     CREATE_TRY(hip_ok(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking),
                       "hipStreamCreate"));
     ctx->stream = ctx->own_stream;
-    const size_t kv = (size_t)K * V;
+    const size_t kv = (size_t)K * V, wk = (size_t)V * ctx->ldk;
     CREATE_TRY(dev_alloc(ctx, &ctx->d_eta, kv));
-    CREATE_TRY(dev_alloc(ctx, &ctx->d_elog, kv));
-    CREATE_TRY(dev_alloc(ctx, &ctx->d_expElog, kv));
-    CREATE_TRY(dev_alloc(ctx, &ctx->d_sstats, kv));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_elog, wk));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_expElog, wk));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_sstats, wk));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_kv_scratch, kv));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_shift, (size_t)V));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_beta, (size_t)V));
@@ -338,7 +434,7 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     CREATE_TRY(dev_alloc(ctx, &ctx->d_small, (size_t)(4 * K + 16)));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_partial, (size_t)1024 * K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_flag_count, (size_t)1));
-    CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_sstats, 0, kv * sizeof(double), ctx->stream),
+    CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_sstats, 0, wk * sizeof(double), ctx->stream),
                       "hipMemsetAsync"));
 #undef CREATE_TRY
     *out = ctx;
@@ -409,6 +505,8 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
     const int64_t nnz = doc_ptr[D];
     if (max_terms > (1 << 24))
         return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: a document has %lld distinct terms", (long long)max_terms);
+    if (nnz > INT32_MAX)
+        return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: %lld distinct (doc, term) pairs exceed 2^31-1 per device; shard the corpus", (long long)nnz);
     if (nnz > 0 && (!term_id || !term_ct))
         return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: NULL term arrays");
     int64_t tokens = 0;
@@ -454,6 +552,8 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
     A(dev_alloc(ctx, &c->d_status, (size_t)D));
     A(dev_alloc(ctx, &c->d_flag_list, (size_t)D));
     A(dev_alloc(ctx, &c->d_scalars, (size_t)4));
+    A(dev_alloc(ctx, &c->d_tfinal, (size_t)D * ctx->ldk));
+    A(dev_alloc(ctx, &c->d_rfinal, (size_t)nnz));
     if (rc != PYLDA_OK) {
         pylda_corpus_destroy(c);
         return rc;
@@ -471,6 +571,8 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
         pylda_corpus_destroy(c);
         return rc;
     }
+    c->h_doc_ptr.assign(doc_ptr, doc_ptr + D + 1);     // for the lazy postings build
+    c->h_term_id.assign(term_id, term_id + nnz);
     *out = c;
     return PYLDA_OK;
 }
@@ -485,6 +587,8 @@ void pylda_corpus_destroy(pylda_corpus* c)
     dev_free(c->d_doc_ptr); dev_free(c->d_term_id); dev_free(c->d_term_ct); dev_free(c->d_order);
     dev_free(c->d_gamma); dev_free(c->d_doc_ll); dev_free(c->d_doc_wll); dev_free(c->d_iters);
     dev_free(c->d_status); dev_free(c->d_flag_list); dev_free(c->d_scalars);
+    dev_free(c->d_tfinal); dev_free(c->d_rfinal); dev_free(c->d_post_doc); dev_free(c->d_post_pos);
+    dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial);
     delete c;
 }
 
@@ -553,13 +657,13 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
 
     int rc = enqueue_prepare(ctx, heldout != 0);                      // :152-155
     if (rc != PYLDA_OK) return rc;
-    if (!heldout)
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_sstats, 0, (size_t)K * V * sizeof(double), ctx->stream));  // :147
+    if (!heldout && (rc = build_postings(c)) != PYLDA_OK) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_flag_count, 0, sizeof(int32_t), ctx->stream));
 
     EstepParams p;
     p.K = K;
     p.V = V;
+    p.ldk = ctx->ldk;
     p.expElog = ctx->d_expElog;
     p.shift = ctx->d_shift;
     p.topic_lse = ctx->d_topic_lse;
@@ -580,7 +684,8 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     p.doc_ll = c->d_doc_ll;
     p.doc_words_ll = c->d_doc_wll;
     p.iters = c->d_iters;
-    p.sstats = ctx->d_sstats;
+    p.tfinal = c->d_tfinal;
+    p.rfinal = c->d_rfinal;
     p.status = c->d_status;
 
     if (c->plan_epoch != ctx->plan_epoch) build_plan(c);
@@ -616,6 +721,14 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         ctx->estep_calls += 1;
     }
 
+    // sufficient statistics (:207): gather pass over the postings, no atomics
+    if (!heldout) {
+        if (ctx->force_logspace) {
+            HIP_TRY(ctx, hipMemsetAsync(c->d_rfinal, 0, (size_t)c->nnz * sizeof(double), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(c->d_tfinal, 0, (size_t)c->D * ctx->ldk * sizeof(double), ctx->stream));
+        }
+        if ((rc = enqueue_sstats_gather(ctx, c)) != PYLDA_OK) return rc;
+    }
     // safety net: documents the linear-space kernels flagged are redone in log space
     if (c->D > 0) {
         hipLaunchKernelGGL(flagged_collect_kernel, dim3((unsigned)((c->D + 255) / 256)), dim3(256), 0,
@@ -623,7 +736,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         p.order = nullptr;
         const unsigned grid = (unsigned)std::min<int64_t>(c->D, 4 * (int64_t)ctx->num_cu);
         hipLaunchKernelGGL(estep_logspace_kernel, dim3(grid), dim3(256), logspace_lds_bytes(K),
-                           ctx->stream, p, ctx->d_elog, c->d_flag_list, ctx->d_flag_count);
+                           ctx->stream, p, ctx->d_elog, ctx->d_sstats, c->d_flag_list, ctx->d_flag_count);
     }
     hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_doc_ll, c->D,
                        c->d_scalars);
@@ -663,7 +776,7 @@ int pylda_get_sstats(pylda_ctx* ctx, double* sstats_kv)
     const int K = ctx->K, V = ctx->V;
     // device layout is (V, K); hand back numpy's (K, V)
     hipLaunchKernelGGL(transpose_kernel, dim3((K + 31) / 32, (V + 31) / 32), dim3(256), 0, ctx->stream,
-                       ctx->d_sstats, V, K, ctx->d_kv_scratch);
+                       ctx->d_sstats, V, K, ctx->ldk, V, ctx->d_kv_scratch);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(sstats_kv, ctx->d_kv_scratch, (size_t)K * V * sizeof(double),
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -680,8 +793,9 @@ int pylda_set_sstats(pylda_ctx* ctx, const double* sstats_kv)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_kv_scratch, sstats_kv, (size_t)K * V * sizeof(double),
                                 hipMemcpyHostToDevice, ctx->stream));
     // numpy's (K, V) -> device layout (V, K)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_sstats, 0, (size_t)V * ctx->ldk * sizeof(double), ctx->stream));
     hipLaunchKernelGGL(transpose_kernel, dim3((V + 31) / 32, (K + 31) / 32), dim3(256), 0, ctx->stream,
-                       ctx->d_kv_scratch, K, V, ctx->d_sstats);
+                       ctx->d_kv_scratch, K, V, V, ctx->ldk, ctx->d_sstats);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_sstats = true;
@@ -739,6 +853,7 @@ int pylda_estep_host(pylda_ctx* ctx, pylda_corpus* c, const double* alpha_k, con
     return PYLDA_OK;
 }
 
+int pylda_table_stride(const pylda_ctx* ctx) { return ctx ? ctx->ldk : 0; }
 void* pylda_sstats_device(pylda_ctx* ctx) { return ctx ? ctx->d_sstats : nullptr; }
 void* pylda_eta_device(pylda_ctx* ctx) { return ctx ? ctx->d_eta : nullptr; }
 void* pylda_gamma_device(pylda_corpus* c) { return c ? c->d_gamma : nullptr; }
@@ -774,7 +889,7 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* t
     double* d_alpha_ss = ctx->d_small + K;       // K
     hipLaunchKernelGGL(mstep_topic_ll_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_eta, K, V, d_per_topic);   // :224 (old eta)
     hipLaunchKernelGGL(mstep_update_eta_kernel, dim3((K + 31) / 32, (V + 31) / 32), dim3(256), 0, ctx->stream,
-                       ctx->d_sstats, ctx->d_beta, K, V, ctx->d_eta);                                               // :226
+                       ctx->d_sstats, ctx->d_beta, K, V, ctx->ldk, ctx->d_eta);                                               // :226
     int nblocks = 0;
     if (alpha_ss_k) {
         nblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (c->D + 3) / 4));

@@ -13,7 +13,8 @@ constexpr int kWave = 64;   // CDNA4 wavefront width
 struct EstepParams {
     int K;
     int V;
-    const double* expElog;    // V x K : exp(E_log_eta[k][w] - shift[w])
+    int ldk;                  // row stride of the word-major tables (K rounded up; padding is 0)
+    const double* expElog;    // V x ldk : exp(E_log_eta[k][w] - shift[w])
     const double* shift;      // V     : max_k E_log_eta[k][w]
     const double* topic_lse;  // K     : logsumexp_v E_log_eta[k][:]  (held-out only, :155)
     const double* alpha;      // K
@@ -29,7 +30,8 @@ struct EstepParams {
     double* doc_ll;           // D out: this document's terms of :195-199
     double* doc_words_ll;     // D out: this document's term of :204
     int32_t* iters;           // D out: inner iterations executed
-    double* sstats;           // V x K, += phi * count                (:207)
+    double* tfinal;           // D x ldk out: t[k] of the last executed iteration (training)
+    double* rfinal;           // nnz out: count / normaliser of the last executed iteration
     int32_t* status;          // D out: 0 ok, 1 = linear-space normaliser under/overflowed
     int n_cap;                // max distinct terms of any document in this launch
     int tile_stride;          // LDS row stride in doubles (odd)

@@ -21,7 +21,6 @@
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace pylda {
 
@@ -63,7 +62,7 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
     const int doc = p.order[blockIdx.x];
     const int64_t lo = p.doc_ptr[doc];
     const int N = (int)(p.doc_ptr[doc + 1] - lo);
-    const int stride = TILE_GLOBAL ? K : p.tile_stride;
+    const int stride = TILE_GLOBAL ? p.ldk : p.tile_stride;
 
     const GenericLds L = generic_lds_layout(K, p.n_cap, p.tile_stride, NT, TILE_GLOBAL);
     double* tile = reinterpret_cast<double*>(smem + L.tile);
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
     // ---- gather the B tile: rows are contiguous K doubles in the table ----
     if constexpr (!TILE_GLOBAL) {
         for (int n = g; n < N; n += G) {
-            const double* src = p.expElog + (size_t)ids[n] * K;
+            const double* src = p.expElog + (size_t)ids[n] * p.ldk;
             double* dst = tile + (size_t)n * stride;
             for (int k = kl; k < K; k += KL) dst[k] = src[k];
         }
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
     __syncthreads();
 
     auto row = [&](int n) -> const double* {
-        if constexpr (TILE_GLOBAL) return p.expElog + (size_t)ids[n] * K;
+        if constexpr (TILE_GLOBAL) return p.expElog + (size_t)ids[n] * p.ldk;
         else return tile + (size_t)n * stride;
     };
 
@@ -179,6 +178,10 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
     // finished here: it is flagged and redone by the log-space kernel.
     bad = __syncthreads_or(bad);
     if (bad) {
+        if (!p.heldout) {      // contributes nothing to the gather pass; the log-space kernel adds it
+            for (int n = tid; n < N; n += NT) p.rfinal[lo + n] = 0.0;
+            for (int k = tid; k < p.ldk; k += NT) p.tfinal[(size_t)doc * p.ldk + k] = 0.0;
+        }
         if (tid == 0) p.status[doc] = 1;
         return;
     }
@@ -190,7 +193,6 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
     for (int n = g; n < N; n += G) {
         const double* b = row(n);
         const double rn = r[n], ln = lognrm[n];
-        const size_t base = (size_t)ids[n] * K;
         const double sh = p.heldout ? p.shift[ids[n]] : 0.0;
         for (int kk = kl; kk < K; kk += KL) {
             const double bv = b[kk];
@@ -200,11 +202,17 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
                 ent = fma(pc, lb + lt[kk] - ln, ent);      // :199
                 if (p.heldout) wll = fma(pc, lb + sh - p.topic_lse[kk], wll);   // :204
             }
-            if (!p.heldout && pc != 0.0) unsafeAtomicAdd(&p.sstats[base + kk], pc);   // :207
         }
     }
     ent = block_sum<NT>(ent, scratch);
     wll = block_sum<NT>(wll, scratch);
+    // The sufficient statistics (:207) are phi*count = B[w][k] * t[k] * r[n]: the
+    // factors t (per document) and r (per term) are handed to the gather pass
+    // (sstats_kernels.h), which sums them word by word without atomics.
+    if (!p.heldout) {
+        for (int n = tid; n < N; n += NT) p.rfinal[lo + n] = r[n];
+        for (int k = tid; k < p.ldk; k += NT) p.tfinal[(size_t)doc * p.ldk + k] = k < K ? t[k] : 0.0;
+    }
 
     double lg = 0.0, gs = 0.0;
     for (int k = tid; k < K; k += NT) {

@@ -9,7 +9,9 @@
 // iteration), so it is slow and never on the measured path.
 //
 // One workgroup (4 wavefronts) per document; a wavefront owns a word at a
-// time, lanes stride over topics.
+// time, lanes stride over topics.  Its sufficient statistics have no t*r
+// factorisation in linear space: it runs AFTER the gather pass and adds them
+// (fp64 atomics, rare) straight into the finished V x ldk table.
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
@@ -24,7 +26,7 @@ __host__ __device__ inline size_t logspace_lds_bytes(int K)
 }
 
 __device__ inline void logspace_document(const EstepParams& p, const double* __restrict__ elog_wk,
-                                         int doc, char* smem)
+                                         double* __restrict__ sstats_extra, int doc, char* smem)
 {
     constexpr int NT = 256, NW = 4;
     const int K = p.K;
@@ -49,7 +51,7 @@ __device__ inline void logspace_document(const EstepParams& p, const double* __r
         for (int k = lane; k < K; k += kWave) gacc[wave * K + k] = 0.0;
         __syncthreads();
         for (int n = wave; n < N; n += NW) {
-            const double* row = elog_wk + (size_t)p.term_id[lo + n] * K;
+            const double* row = elog_wk + (size_t)p.term_id[lo + n] * p.ldk;
             double m = -INFINITY;
             for (int k = lane; k < K; k += kWave) m = fmax(m, row[k] + psi[k]);   // :177
             m = wave_max(m);
@@ -81,7 +83,7 @@ __device__ inline void logspace_document(const EstepParams& p, const double* __r
     double ent = 0.0, wll = 0.0;
     for (int n = wave; n < N; n += NW) {
         const int id = p.term_id[lo + n];
-        const double* row = elog_wk + (size_t)id * K;
+        const double* row = elog_wk + (size_t)id * p.ldk;
         double m = -INFINITY;
         for (int k = lane; k < K; k += kWave) m = fmax(m, row[k] + psi[k]);
         m = wave_max(m);
@@ -97,7 +99,7 @@ __device__ inline void logspace_document(const EstepParams& p, const double* __r
             ent = fma(c, exp(lp) * lp, ent);                                    // :199
             const double pc = exp(lp + lc);
             if (p.heldout) wll = fma(pc, row[k] + sh - p.topic_lse[k], wll);     // :204
-            else if (pc != 0.0) unsafeAtomicAdd(&p.sstats[(size_t)id * K + k], pc);   // :207
+            else if (pc != 0.0) unsafeAtomicAdd(&sstats_extra[(size_t)id * p.ldk + k], pc);   // :207
         }
     }
     ent = block_sum<NT>(ent, scratch);
@@ -124,13 +126,14 @@ __device__ inline void logspace_document(const EstepParams& p, const double* __r
 // host never has to read the count back inside the hot path.
 __global__ __launch_bounds__(256) void estep_logspace_kernel(EstepParams p,
                                                              const double* __restrict__ elog_wk,
+                                                             double* __restrict__ sstats_extra,
                                                              const int32_t* __restrict__ list,
                                                              const int32_t* __restrict__ count)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = *count;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        logspace_document(p, elog_wk, list[i], smem);
+        logspace_document(p, elog_wk, sstats_extra, list[i], smem);
         __syncthreads();
     }
 }

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void mstep_topic_ll_kernel(const double* __res
 // eta[k][v] = sstats_wk[v][k] + beta[v]                              (:226)
 __global__ __launch_bounds__(256) void mstep_update_eta_kernel(const double* __restrict__ sstats_wk,
                                                                const double* __restrict__ beta,
-                                                               int K, int V,
+                                                               int K, int V, int ldk,
                                                                double* __restrict__ eta)
 {
     __shared__ double tile[32][33];
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void mstep_update_eta_kernel(const double* __r
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int v = v0 + ty + j * 8, k = k0 + tx;
-        if (v < V && k < K) tile[ty + j * 8][tx] = sstats_wk[(size_t)v * K + k];
+        if (v < V && k < K) tile[ty + j * 8][tx] = sstats_wk[(size_t)v * ldk + k];
     }
     __syncthreads();
 #pragma unroll

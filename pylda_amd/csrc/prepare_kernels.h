@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void eta_rowsum_psi_kernel(const double* __res
 // E_log_eta word-major, coalesced along k, through a 32x33 LDS tile.
 __global__ __launch_bounds__(256) void elog_transpose_kernel(const double* __restrict__ eta,
                                                              const double* __restrict__ psi_rowsum,
-                                                             int K, int V,
+                                                             int K, int V, int ldk,
                                                              double* __restrict__ elog_wk)
 {
     __shared__ double tile[32][33];
@@ -50,26 +50,28 @@ __global__ __launch_bounds__(256) void elog_transpose_kernel(const double* __res
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int v = v0 + ty + j * 8, k = k0 + tx;
-        if (k < K && v < V) elog_wk[(size_t)v * K + k] = tile[tx][ty + j * 8];
+        if (k < K && v < V) elog_wk[(size_t)v * ldk + k] = tile[tx][ty + j * 8];
     }
 }
 
 // One wavefront per word row: max-shift and exponentiate in place.
 __global__ __launch_bounds__(256) void row_shift_exp_kernel(double* __restrict__ elog_wk, int K,
-                                                            int V, double* __restrict__ expElog,
+                                                            int V, int ldk,
+                                                            double* __restrict__ expElog,
                                                             double* __restrict__ shift)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int w = blockIdx.x * 4 + threadIdx.x / kWave;
     if (w >= V) return;
-    double* row = elog_wk + (size_t)w * K;
+    double* row = elog_wk + (size_t)w * ldk;
     double m = -INFINITY;
     for (int k = lane; k < K; k += kWave) m = fmax(m, row[k]);
     m = wave_max(m);
-    for (int k = lane; k < K; k += kWave) {
-        const double e = row[k] - m;
+    for (int k = lane; k < ldk; k += kWave) {
+        const bool real = k < K;                     // columns K..ldk-1 are zero padding
+        const double e = real ? row[k] - m : 0.0;
         row[k] = e;
-        expElog[(size_t)w * K + k] = exp(e);
+        expElog[(size_t)w * ldk + k] = real ? exp(e) : 0.0;
     }
     if (lane == 0) shift[w] = m;
 }
@@ -77,23 +79,25 @@ __global__ __launch_bounds__(256) void row_shift_exp_kernel(double* __restrict__
 // topic_lse[k] = logsumexp_v (Elog[v][k] + shift[v]); one workgroup per topic.
 __global__ __launch_bounds__(256) void topic_lse_kernel(const double* __restrict__ elog_wk,
                                                         const double* __restrict__ shift, int K,
-                                                        int V, double* __restrict__ topic_lse)
+                                                        int V, int ldk,
+                                                        double* __restrict__ topic_lse)
 {
     __shared__ double scratch[4];
     const int k = blockIdx.x;
     double m = -INFINITY;
-    for (int v = threadIdx.x; v < V; v += 256) m = fmax(m, elog_wk[(size_t)v * K + k] + shift[v]);
+    for (int v = threadIdx.x; v < V; v += 256) m = fmax(m, elog_wk[(size_t)v * ldk + k] + shift[v]);
     m = block_max<256>(m, scratch);
     double s = 0.0;
-    for (int v = threadIdx.x; v < V; v += 256) s += exp(elog_wk[(size_t)v * K + k] + shift[v] - m);
+    for (int v = threadIdx.x; v < V; v += 256) s += exp(elog_wk[(size_t)v * ldk + k] + shift[v] - m);
     s = block_sum<256>(s, scratch);
     if (threadIdx.x == 0) topic_lse[k] = m + log(s);
 }
 
-// K x V <-> V x K transposes of plain fp64 matrices (sstats export, eta import).
-// in: rows x cols row-major; out: cols x rows row-major.
+// Transposes of plain fp64 matrices (sstats export / import).
+// in: rows x cols with leading dimension in_ld; out: cols x rows with leading dimension out_ld.
 __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, int rows,
-                                                        int cols, double* __restrict__ out)
+                                                        int cols, int in_ld, int out_ld,
+                                                        double* __restrict__ out)
 {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -101,13 +105,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = r0 + ty + j * 8, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + j * 8][tx] = in[(size_t)r * cols + c];
+        if (r < rows && c < cols) tile[ty + j * 8][tx] = in[(size_t)r * in_ld + c];
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = c0 + ty + j * 8, r = r0 + tx;
-        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][ty + j * 8];
+        if (r < rows && c < cols) out[(size_t)c * out_ld + r] = tile[tx][ty + j * 8];
     }
 }
 

@@ -35,7 +35,7 @@ def allreduce_sstats(ctx, group=None):
     """In-place RCCL all-reduce(sum) of the (V, K) sufficient statistics."""
     import torch
     import torch.distributed as dist
-    t = device_tensor(ctx.sstats_device_ptr(), (ctx.K * ctx.V,), torch.device("cuda", ctx.device))
+    t = device_tensor(ctx.sstats_device_ptr(), (ctx.sstats_elements(),), torch.device("cuda", ctx.device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     ctx.mark_device_state(have_sstats=1)
     return t

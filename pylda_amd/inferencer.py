@@ -43,7 +43,7 @@ class Inferencer(object):
                 index = len(self._type_to_index)
                 self._type_to_index[word] = index
                 self._index_to_type[index] = word
-        self._vocab = self._type_to_index.keys()
+        self._vocab = list(self._type_to_index.keys())
 
     def parse_data(self):
         raise NotImplementedError
