@@ -20,6 +20,7 @@
 #include "estep_common.h"
 #include "estep_generic.h"
 #include "estep_logspace.h"
+#include "estep_slab.h"
 #include "mstep_kernels.h"
 #include "prepare_kernels.h"
 #include "sstats_kernels.h"
@@ -34,7 +35,8 @@ enum Variant : int {
     kGeneric64 = 0,    // 1 wavefront / document, tile in LDS
     kGeneric256 = 1,   // 4 wavefronts / document, tile in LDS
     kGeneric512 = 2,   // 8 wavefronts / document, tile in LDS (up to the whole 160 KiB)
-    kGenericGlobal = 3 // tile larger than LDS: rows re-read from the table
+    kGenericGlobal = 3, // tile larger than LDS: rows re-read from the table
+    kSlab = 4           // tile in registers (estep_slab.h); RN picked per launch
 };
 
 struct Launch {
@@ -44,6 +46,8 @@ struct Launch {
     int n_cap;       // largest distinct-term count in the launch
     int tile_stride;
     size_t lds_bytes;
+    int rn;          // slab kernels: words per lane
+    int rk;          // slab kernels: topics per wavefront
 };
 
 }  // namespace
@@ -60,6 +64,7 @@ struct pylda_ctx {
     double* d_eta = nullptr;        // K x V (numpy layout)
     double* d_elog = nullptr;       // V x ldk shifted E_log_eta
     double* d_expElog = nullptr;    // V x ldk
+    double* d_expElog_elog = nullptr; // V x ldk
     double* d_shift = nullptr;      // V
     double* d_psi_rowsum = nullptr; // K
     double* d_topic_lse = nullptr;  // K
@@ -161,15 +166,35 @@ void dev_free(T*& p)
 
 int tile_stride_for(int K) { return K | 1; }   // odd => conflict-free ds_read_b64 along words
 
+// Slab (register-resident) kernel geometry for a document with n distinct terms:
+// prefer 32-topic slabs (fewer wavefronts per document, so the per-wavefront
+// digamma / reduction overhead is amortised over more FMAs) while the slab
+// fits the 256 architectural VGPRs (RN <= 3), else 16-topic slabs (RN <= 6).
+struct SlabGeom { int W, RK, RN; };
+SlabGeom slab_geom_for(const pylda_ctx* ctx, int n)
+{
+    const int need = std::max(1, (n + 63) / 64), ldk = ctx->ldk;
+    if ((ldk == 32 || ldk == 64 || ldk == 128) && need <= 2) return {ldk / 32, 32, need};
+    if (ldk == 16 || ldk == 32 || ldk == 64 || ldk == 128) {
+        if (need <= 4) return {ldk / 16, 16, need};
+        if (need <= 6 && ldk <= 64) return {ldk / 16, 16, 6};
+    }
+    return {0, 0, 0};
+}
+
 // Decide the kernel variant for a document with n distinct terms.
 int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
 {
+    if ((ctx->force_variant < 0 || ctx->force_variant == kSlab) && slab_geom_for(ctx, n).W > 0) {
+        *lds_bytes = 0;
+        return kSlab;
+    }
     const int K = ctx->K, stride = tile_stride_for(K);
     const size_t l64 = generic_lds_layout(K, n, stride, 64, false).total;
     const size_t l256 = generic_lds_layout(K, n, stride, 256, false).total;
     const size_t l512 = generic_lds_layout(K, n, stride, 512, false).total;
     int v;
-    if (ctx->force_variant >= 0) v = ctx->force_variant;
+    if (ctx->force_variant >= 0 && ctx->force_variant != kSlab) v = ctx->force_variant;
     else if (l64 <= 20 * 1024) v = kGeneric64;
     else if (l256 <= 64 * 1024) v = kGeneric256;
     else if (l512 <= ctx->lds_limit) v = kGeneric512;
@@ -204,6 +229,10 @@ void build_plan(pylda_corpus* c)
             size_t lds_j;
             const int vj = choose_variant(ctx, c->h_terms_sorted[j], &lds_j);
             if (vj != v) break;
+            if (v == kSlab) {
+                const SlabGeom gi = slab_geom_for(ctx, c->h_terms_sorted[i]), gj = slab_geom_for(ctx, c->h_terms_sorted[j]);
+                if (gi.RK != gj.RK || gi.RN != gj.RN) break;
+            }
             if (v != kGenericGlobal && lds_first > 4096 && lds_j * 5 < lds_first * 4 &&
                 (j - i) >= 4 * (int64_t)ctx->num_cu)
                 break;
@@ -216,6 +245,8 @@ void build_plan(pylda_corpus* c)
         L.n_cap = std::max(1, c->h_terms_sorted[i]);
         L.tile_stride = tile_stride_for(ctx->K);
         L.lds_bytes = lds_first;
+        L.rn = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RN : 0;
+        L.rk = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RK : 0;
         c->plan.push_back(L);
         i = j;
     }
@@ -234,6 +265,35 @@ int launch_generic(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     return PYLDA_OK;
 }
 
+template <int W, int RK, int RN>
+int launch_slab(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    auto kern = estep_slab_kernel<W, RK, RN>;
+    const size_t lds = SlabLds<W, RK, RN>::total;
+    if (lds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * W), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+int launch_slab_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    const int W = ctx->ldk / L.rk;
+#define SLAB_CASE(w_, rk_, rn_) \
+    if (W == w_ && L.rk == rk_ && L.rn == rn_) return launch_slab<w_, rk_, rn_>(ctx, p, L);
+#define SLAB_RN32(w) SLAB_CASE(w, 32, 1) SLAB_CASE(w, 32, 2)
+#define SLAB_RN16(w) SLAB_CASE(w, 16, 1) SLAB_CASE(w, 16, 2) SLAB_CASE(w, 16, 3) SLAB_CASE(w, 16, 4)
+    SLAB_RN32(1) SLAB_RN32(2) SLAB_RN32(4)
+    SLAB_RN16(1) SLAB_RN16(2) SLAB_RN16(4) SLAB_RN16(8)
+    SLAB_CASE(1, 16, 6) SLAB_CASE(2, 16, 6) SLAB_CASE(4, 16, 6)
+#undef SLAB_RN16
+#undef SLAB_RN32
+#undef SLAB_CASE
+    return fail(ctx, PYLDA_ERR_STATE, "no slab kernel for W=%d RK=%d RN=%d", W, L.rk, L.rn);
+}
+
 int enqueue_prepare(pylda_ctx* ctx, bool heldout)
 {
     const int K = ctx->K, V = ctx->V;
@@ -242,7 +302,7 @@ int enqueue_prepare(pylda_ctx* ctx, bool heldout)
     hipLaunchKernelGGL(elog_transpose_kernel, dim3((V + 31) / 32, (K + 31) / 32), dim3(256), 0,
                        ctx->stream, ctx->d_eta, ctx->d_psi_rowsum, K, V, ctx->ldk, ctx->d_elog);
     hipLaunchKernelGGL(row_shift_exp_kernel, dim3((V + 3) / 4), dim3(256), 0, ctx->stream,
-                       ctx->d_elog, K, V, ctx->ldk, ctx->d_expElog, ctx->d_shift);
+                       ctx->d_elog, K, V, ctx->ldk, ctx->d_expElog, ctx->d_expElog_elog, ctx->d_shift);
     if (heldout)
         hipLaunchKernelGGL(topic_lse_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_elog,
                            ctx->d_shift, K, V, ctx->ldk, ctx->d_topic_lse);
@@ -424,6 +484,7 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     CREATE_TRY(dev_alloc(ctx, &ctx->d_eta, kv));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_elog, wk));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_expElog, wk));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_expElog_elog, wk));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_sstats, wk));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_kv_scratch, kv));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_shift, (size_t)V));
@@ -448,7 +509,7 @@ void pylda_destroy(pylda_ctx* ctx)
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     drain_events(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
-    dev_free(ctx->d_eta); dev_free(ctx->d_elog); dev_free(ctx->d_expElog); dev_free(ctx->d_sstats);
+    dev_free(ctx->d_eta); dev_free(ctx->d_elog); dev_free(ctx->d_expElog); dev_free(ctx->d_expElog_elog); dev_free(ctx->d_sstats);
     dev_free(ctx->d_kv_scratch); dev_free(ctx->d_shift); dev_free(ctx->d_beta);
     dev_free(ctx->d_psi_rowsum); dev_free(ctx->d_topic_lse); dev_free(ctx->d_alpha);
     dev_free(ctx->d_small); dev_free(ctx->d_partial); dev_free(ctx->d_flag_count);
@@ -478,7 +539,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kGenericGlobal)
+        if (value < -1 || value > kSlab)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
@@ -665,6 +726,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     p.V = V;
     p.ldk = ctx->ldk;
     p.expElog = ctx->d_expElog;
+    p.expElog_elog = ctx->d_expElog_elog;
     p.shift = ctx->d_shift;
     p.topic_lse = ctx->d_topic_lse;
     p.alpha = ctx->d_alpha;
@@ -710,6 +772,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kGeneric64: rc = launch_generic<64, false>(ctx, p, L); break;
             case kGeneric256: rc = launch_generic<256, false>(ctx, p, L); break;
             case kGeneric512: rc = launch_generic<512, false>(ctx, p, L); break;
+            case kSlab: rc = launch_slab_any(ctx, p, L); break;
             default: rc = launch_generic<256, true>(ctx, p, L); break;
             }
             if (rc != PYLDA_OK) return rc;

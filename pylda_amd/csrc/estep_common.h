@@ -15,6 +15,7 @@ struct EstepParams {
     int V;
     int ldk;                  // row stride of the word-major tables (K rounded up; padding is 0)
     const double* expElog;    // V x ldk : exp(E_log_eta[k][w] - shift[w])
+    const double* expElog_elog; // V x ldk : expElog * (E_log_eta - shift)   ("B log B", entropy term)
     const double* shift;      // V     : max_k E_log_eta[k][w]
     const double* topic_lse;  // K     : logsumexp_v E_log_eta[k][:]  (held-out only, :155)
     const double* alpha;      // K

@@ -1,0 +1,322 @@
+// Register-resident E-step kernel ("slab"): the N_d x K tile of
+// B = exp(E_log_eta - shift) lives in VGPRs for the whole inner loop.
+//
+// Why registers: on CDNA4 the vector register file (512 KiB per CU) is the
+// largest on-chip memory, 3x the LDS, and a v_fma_f64 whose operands are all
+// registers is the only form that can run at the fp64 FMA rate - an LDS
+// operand costs 8 bytes of LDS bandwidth per FMA, twice what the CU has.
+//
+// One workgroup = one document = W wavefronts.
+//   wavefront w   owns topics  [w*RK, (w+1)*RK)         (a "slab" of the tile)
+//   lane l        owns words   l, l+64, ..., l+64*(RN-1)
+//   => lane registers hold B[RN][RK]; t[k] of the wave's topics is broadcast
+//      to every lane with v_readlane (wave-uniform operand of the FMA).
+//
+// One inner iteration (variational_bayes.py:177-190), exp-hoisted as in
+// estep_generic.h, with t[k] = exp(psi(gamma_k) - psi(sum gamma)) so that no
+// per-iteration max over topics is needed (sum gamma is invariant: sum alpha
+// + #tokens):
+//   A. p[n] = sum_{k in slab} B[n][k] t[k]      in-lane FMAs      -> LDS partial[w][n]
+//      barrier
+//   B. nrm[n] = sum_w partial[w][n];  r[n] = c[n] / nrm[n]
+//      q[k] = sum_{n in lane} r[n] B[n][k]      in-lane FMAs
+//      s[k] = sum_lanes q[k]                    2 permlane-swap levels + LDS transpose
+//      gamma'_k = alpha_k + t[k] s[k]           every lane group of 64/RK lanes owns a topic
+//      barrier (convergence decision, :187-190)
+// Everything is summed in a fixed order: results are bitwise reproducible.
+#pragma once
+#include "estep_common.h"
+#include "special_device.h"
+
+namespace pylda {
+
+template <int W, int RK, int RN>
+struct SlabLds {
+    static constexpr int kWords = kWave * RN;
+    static constexpr size_t partial = 0;                                         // [2][W][kWords]
+    static constexpr size_t red = partial + (size_t)2 * W * kWords * 8;          // [W][RK][17]
+    static constexpr size_t chg = red + (size_t)W * RK * 17 * 8;                 // [2][W]
+    static constexpr size_t misc = chg + (size_t)2 * W * 8 + 16;                 // [8][W]
+    static constexpr size_t total = ((misc + (size_t)8 * W * 8) + 15) & ~(size_t)15;
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// a' = [a.lo32 | b.lo32], b' = [a.hi32 | b.hi32] (halves of the wavefront); returns a' + b'.
+__device__ __forceinline__ double swap32_add(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// the same with 16-lane rows: swaps odd rows of a with even rows of b.
+__device__ __forceinline__ double swap16_add(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// 1/x for normal positive x: v_rcp_f64 seed + two Newton steps (the same
+// refinement the compiler's IEEE division uses, without the scaling fix-ups).
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
+template <int W, int RK, int RN>
+__global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
+{
+    using L = SlabLds<W, RK, RN>;
+    constexpr int NT = kWave * W;
+    constexpr int LP = kWave / RK;          // lanes that share one topic in the gamma update
+    constexpr int Q = RK / 4;               // values per lane after the two swap levels
+    static_assert(RK == 16 || RK == 32, "slab width");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* partial = reinterpret_cast<double*>(smem + L::partial);
+    double* red = reinterpret_cast<double*>(smem + L::red);
+    double* chg = reinterpret_cast<double*>(smem + L::chg);
+    double* misc = reinterpret_cast<double*>(smem + L::misc);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid / kWave;
+    const int K = p.K, ldk = p.ldk;
+    const int doc = p.order[blockIdx.x];
+    const int64_t lo = p.doc_ptr[doc];
+    const int N = (int)(p.doc_ptr[doc + 1] - lo);
+    const int k0 = wave * RK;
+
+    // ---- load the slab: this lane's words x this wave's topics ----
+    double B[RN][RK];
+    double cnt[RN];
+    int wid[RN];
+    double total = 0.0;
+#pragma unroll
+    for (int i = 0; i < RN; ++i) {
+        const int n = lane + kWave * i;
+        const bool live = n < N;
+        wid[i] = live ? p.term_id[lo + n] : 0;
+        cnt[i] = live ? (double)p.term_ct[lo + n] : 0.0;
+        total += cnt[i];
+        const double2* src = reinterpret_cast<const double2*>(p.expElog + (size_t)wid[i] * ldk + k0);
+#pragma unroll
+        for (int j = 0; j < RK / 2; ++j) {
+            const double2 v = live ? src[j] : make_double2(0.0, 0.0);
+            B[i][2 * j] = v.x;
+            B[i][2 * j + 1] = v.y;
+        }
+    }
+    total = wave_sum(total);                                              // :162 (every wave sees all words)
+
+    // ---- per-topic state: lane group g = lane / LP owns topic k0 + g ----
+    const int kt = k0 + lane / LP;
+    const bool topic_live = kt < K;
+    const double alpha_k = topic_live ? p.alpha[kt] : 1.0;
+    double gam = alpha_k + total / K;                                     // :165
+    // sum_k gamma_k is invariant under the update: sum alpha + #tokens
+    double asum = 0.0;
+    for (int k = lane; k < K; k += kWave) asum += p.alpha[k];
+    asum = wave_sum(asum);
+    const double psi_total = digamma(asum + total);
+
+    double tv = 0.0, gam_prev = gam;
+    double r[RN], nrm[RN];
+#pragma unroll
+    for (int i = 0; i < RN; ++i) r[i] = nrm[i] = 0.0;
+    int it = 0;
+    int bad = 0;
+    while (it < p.max_iter) {                                             // :174
+        const int buf = it & 1;
+        // t[k] = exp(psi(gamma_k) - psi(sum gamma))  (the constant cancels in :182)
+        gam_prev = gam;
+        tv = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
+        double ts[RK];
+#pragma unroll
+        for (int j = 0; j < RK; ++j) ts[j] = readlane_f64(tv, j * LP);
+
+        // A. partial normalisers of this slab
+        double* mine = partial + ((size_t)buf * W + wave) * L::kWords;
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < RK; j += 2) {
+                a0 = fma(B[i][j], ts[j], a0);
+                a1 = fma(B[i][j + 1], ts[j + 1], a1);
+            }
+            mine[lane + kWave * i] = a0 + a1;
+        }
+        __syncthreads();
+
+        // B. full normalisers, r = count / nrm
+        const double* all = partial + (size_t)buf * W * L::kWords;
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) s += all[(size_t)w * L::kWords + lane + kWave * i];
+            const bool live = lane + kWave * i < N;
+            if (live && !(s > 1e-280 && s < 1e300)) bad = 1;
+            nrm[i] = s;
+            r[i] = live ? cnt[i] * fast_rcp(s) : 0.0;
+        }
+        // q[k] = sum over this lane's words; s[k] = sum over lanes: two transposing
+        // swap levels (topic m pairs with m + RK/2, then with m + RK/4) ...
+        double u[RK / 2];
+#pragma unroll
+        for (int m = 0; m < RK / 2; ++m) {
+            double a = r[0] * B[0][m], b = r[0] * B[0][m + RK / 2];
+#pragma unroll
+            for (int i = 1; i < RN; ++i) {
+                a = fma(r[i], B[i][m], a);
+                b = fma(r[i], B[i][m + RK / 2], b);
+            }
+            u[m] = swap32_add(a, b);
+        }
+        double v[Q];
+#pragma unroll
+        for (int m = 0; m < Q; ++m) v[m] = swap16_add(u[m], u[m + Q]);
+        // ... lane (row r4 = lane/16, column c = lane%16) now holds, for m < Q, topic
+        // m + (r4&1)*Q + (r4>>1)*RK/2 summed over the 4 lanes congruent to c mod 16;
+        // finish through a (RK x 16, stride 17) LDS transpose.
+        double* myred = red + (size_t)wave * RK * 17;
+        {
+            const int r4 = lane >> 4, c = lane & 15;
+            const int tbase = (r4 & 1) * Q + (r4 >> 1) * (RK / 2);
+#pragma unroll
+            for (int m = 0; m < Q; ++m) myred[(tbase + m) * 17 + c] = v[m];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double s;
+        {
+            const int g = lane / LP, part = lane % LP;
+            const double* src = myred + g * 17 + part * (16 / LP);
+            s = src[0];
+#pragma unroll
+            for (int x = 1; x < 16 / LP; ++x) s += src[x];
+#pragma unroll
+            for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m, kWave);
+        }
+        // gamma update, this lane group's topic
+        const double gnew = fma(tv, s, alpha_k);                          // :185
+        double diff = (topic_live && (lane % LP) == 0) ? fabs(gnew - gam) : 0.0;   // :187
+        gam = gnew;                                                       // :188
+        diff = wave_sum(diff);
+        if (lane == 0) chg[buf * W + wave] = diff;
+        ++it;
+        __syncthreads();
+        double change = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) change += chg[buf * W + w];
+        if (change / K <= p.tol) break;                                   // :189
+    }
+
+    bad = __syncthreads_or(bad);
+    if (bad) {
+        if (!p.heldout) {      // contributes nothing to the gather pass; the log-space kernel adds it
+            for (int n = tid; n < N; n += NT) p.rfinal[lo + n] = 0.0;
+            for (int k = tid; k < ldk; k += NT) p.tfinal[(size_t)doc * ldk + k] = 0.0;
+        }
+        if (tid == 0) p.status[doc] = 1;
+        return;
+    }
+
+    // ---- document terms (:195-204) with the last phi = B t r ----
+    //   sum_n c_n sum_k phi log phi = sum_n r_n sum_k (B log B)[n][k] t_k
+    //                               + sum_k log t_k (gamma_k - alpha_k) - sum_n c_n log nrm_n
+    // (rows of phi sum to one; columns of phi*c sum to gamma - alpha).
+    double ts[RK];
+#pragma unroll
+    for (int j = 0; j < RK; ++j) ts[j] = readlane_f64(tv, j * LP);
+    double term1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < RN; ++i) {
+        if (lane + kWave * i < N) {
+            const double2* src = reinterpret_cast<const double2*>(p.expElog_elog + (size_t)wid[i] * ldk + k0);
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < RK / 2; ++j) {
+                const double2 g2 = src[j];
+                a0 = fma(g2.x, ts[2 * j], a0);
+                a1 = fma(g2.y, ts[2 * j + 1], a1);
+            }
+            term1 = fma(r[i], a0 + a1, term1);
+        }
+    }
+    const bool owner = topic_live && (lane % LP) == 0;
+    const double ltv = digamma(gam_prev) - psi_total;                     // log t of the last iteration
+    double term2 = owner ? ltv * (gam - alpha_k) : 0.0;
+    double lse_term = (owner && p.heldout) ? p.topic_lse[kt] * (gam - alpha_k) : 0.0;
+    double lgam = owner ? lgamma_pos(gam) : 0.0;
+    double gsum = owner ? gam : 0.0;
+    double term3 = 0.0, shift_term = 0.0;
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < RN; ++i) {
+            if (lane + kWave * i < N) {
+                term3 = fma(cnt[i], log(nrm[i]), term3);
+                if (p.heldout) shift_term = fma(cnt[i], p.shift[wid[i]], shift_term);
+            }
+        }
+    }
+    term1 = wave_sum(term1);
+    term2 = wave_sum(term2);
+    lse_term = wave_sum(lse_term);
+    lgam = wave_sum(lgam);
+    gsum = wave_sum(gsum);
+    term3 = wave_sum(term3);
+    shift_term = wave_sum(shift_term);
+    if (lane == 0) {
+        misc[0 * W + wave] = term1;
+        misc[1 * W + wave] = term2;
+        misc[2 * W + wave] = lse_term;
+        misc[3 * W + wave] = lgam;
+        misc[4 * W + wave] = gsum;
+        misc[5 * W + wave] = term3;
+        misc[6 * W + wave] = shift_term;
+    }
+    if (owner) p.gamma[(size_t)doc * K + kt] = gam;
+    if (!p.heldout) {
+        if ((lane % LP) == 0) p.tfinal[(size_t)doc * ldk + kt] = tv;     // padded topics: 0
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < RN; ++i)
+                if (lane + kWave * i < N) p.rfinal[lo + lane + kWave * i] = r[i];
+        }
+        for (int k = W * RK + tid; k < ldk; k += NT) p.tfinal[(size_t)doc * ldk + k] = 0.0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t1 = 0.0, t2 = 0.0, tl = 0.0, lg = 0.0, gs = 0.0, t3 = 0.0, sh = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            t1 += misc[0 * W + w];
+            t2 += misc[1 * W + w];
+            tl += misc[2 * W + w];
+            lg += misc[3 * W + w];
+            gs += misc[4 * W + w];
+            t3 += misc[5 * W + w];
+            sh += misc[6 * W + w];
+        }
+        const double ent = t1 + t2 - t3;
+        p.doc_ll[doc] = p.alpha_term + lg - lgamma_pos(gs) - ent;        // :195-199
+        p.doc_words_ll[doc] = p.heldout ? t1 + sh - tl : 0.0;            // :204
+        p.iters[doc] = it;
+        p.status[doc] = 0;
+    }
+}
+
+}  // namespace pylda

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void elog_transpose_kernel(const double* __res
 __global__ __launch_bounds__(256) void row_shift_exp_kernel(double* __restrict__ elog_wk, int K,
                                                             int V, int ldk,
                                                             double* __restrict__ expElog,
+                                                            double* __restrict__ expElog_elog,
                                                             double* __restrict__ shift)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -71,7 +72,9 @@ __global__ __launch_bounds__(256) void row_shift_exp_kernel(double* __restrict__
         const bool real = k < K;                     // columns K..ldk-1 are zero padding
         const double e = real ? row[k] - m : 0.0;
         row[k] = e;
-        expElog[(size_t)w * ldk + k] = real ? exp(e) : 0.0;
+        const double b = real ? exp(e) : 0.0;
+        expElog[(size_t)w * ldk + k] = b;
+        expElog_elog[(size_t)w * ldk + k] = b > 0.0 ? b * e : 0.0;    // 0 * (-745..) -> 0, as exp(lp)*lp does at :199
     }
     if (lane == 0) shift[w] = m;
 }

@@ -52,6 +52,46 @@ __device__ __forceinline__ double digamma(double x)
     return digamma_asymptotic(x + 10.0) - shift;
 }
 
+// exp(psi(x) - c) for x > 0 without the log/exp round trip:
+//   psi(y) = log y - 1/(2y) - S(y)   =>   exp(psi(y) - z) = y * exp(-1/(2y) - S(y) - z)
+// with y = x (x >= 10) or y = x + 10 and the folded recurrence shift added to
+// z.  Branch-free: divergent lanes (gamma ~ alpha next to gamma ~ 100) cost
+// nothing extra.
+__device__ __forceinline__ double exp_digamma_minus(double x, double c)
+{
+    const bool small = x < 10.0;
+    const double y = small ? x + 10.0 : x;
+    // folded recurrence sum_{i<10} 1/(x+i), see digamma()
+    const double q0 = x * (x + 9.0);
+    const double q1 = (x + 1.0) * (x + 8.0);
+    const double q2 = (x + 2.0) * (x + 7.0);
+    const double q3 = (x + 3.0) * (x + 6.0);
+    const double q4 = (x + 4.0) * (x + 5.0);
+    const double n12 = q1 + q2, d12 = q1 * q2;
+    const double n34 = q3 + q4, d34 = q3 * q4;
+    const double n1234 = fma(n12, d34, n34 * d12), d1234 = d12 * d34;
+    const double num = fma(n1234, q0, d1234), den = d1234 * q0;
+    // one reciprocal serves both 1/den and 1/y:  1/(den*y), Newton-refined
+    const double prod = den * y;
+    double rc = __builtin_amdgcn_rcp(prod);
+    double e = fma(-prod, rc, 1.0);
+    rc = fma(rc, e, rc);
+    e = fma(-prod, rc, 1.0);
+    rc = fma(rc, e, rc);
+    const double inv = rc * den;                    // 1/y
+    const double shift = small ? (2.0 * x + 9.0) * (num * (rc * y)) : 0.0;
+    const double w = inv * inv;
+    double s = 1.0 / 12.0;
+    s = fma(-s, w, 691.0 / 32760.0);
+    s = fma(-s, w, 1.0 / 132.0);
+    s = fma(-s, w, 1.0 / 240.0);
+    s = fma(-s, w, 1.0 / 252.0);
+    s = fma(-s, w, 1.0 / 120.0);
+    s = fma(-s, w, 1.0 / 12.0);
+    const double tail = fma(-s, w, -0.5 * inv) - shift - c;     // psi(x) - log(y) - c
+    return y * exp(tail);
+}
+
 // ln Gamma(x), x > 0: Stirling series for x >= 12, otherwise shifted up by
 // the recurrence lnG(x) = lnG(x+m) - ln(x (x+1) ... (x+m-1)).
 __device__ __forceinline__ double lgamma_stirling(double x)

@@ -56,6 +56,8 @@ def csr_slice(doc_ptr, term_id, term_ct, docs):
     return np.array(ptr, dtype=np.int64), cat(ids, np.int32), cat(cts, np.int32)
 
 
-def rel_err(a, b):
+def rel_err(a, b, floor=1e-9):
+    """Largest |a-b| / max(|b|, floor): relative error with an absolute floor, so that
+    quantities that are analytically zero (K=1 log-likelihoods) compare absolutely."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
-    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)) if a.size else 0.0
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)) if a.size else 0.0

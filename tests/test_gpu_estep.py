@@ -92,7 +92,7 @@ def test_ap_heldout_k10_matches_reference_goldens(capi, ap_test):
     assert abs(out["words_log_likelihood"] - float(g["corpus_words_ll"])) < 1e-9 * abs(float(g["corpus_words_ll"]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_every_kernel_variant_agrees(capi, ap_train, variant):
     g = ap_train
     docs = list(range(0, 2000, 10))
@@ -175,6 +175,35 @@ def test_random_corpora_against_c_oracle(capi, K, V, D, mean_len):
     held = run(capi, alpha, eta, ptr, ids, cts, heldout=True)
     check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"],
                   ll_key="doc_words_ll", min_same=0.95)
+
+
+@pytest.mark.parametrize("K,V,mean_len", [(10, 300, 20), (16, 300, 150), (17, 400, 90), (32, 500, 260),
+                                          (50, 600, 120), (64, 700, 330), (100, 900, 200), (128, 900, 150),
+                                          (128, 1200, 230), (128, 1200, 40)])
+def test_register_resident_slab_kernels(capi, K, V, mean_len):
+    """The slab kernels (tile in VGPRs) over every (wavefronts, slab width, words per lane) geometry,
+    against the C oracle and against the generic LDS kernel."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(K * 7 + mean_len)
+    ptr, ids, cts = random_corpus(rng, 40, V, mean_len, zipf=0.8)
+    eta = rng.gamma(100.0, 0.01, (K, V))
+    eta[:, rng.choice(V, V // 4, replace=False)] = 1.0 / V
+    alpha = rng.uniform(0.05, 1.5, K)
+    ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
+    out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 4)])
+    check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
+    assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+    gen = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 1)])
+    assert np.array_equal(out["iters"], gen["iters"])
+    assert rel_err(out["gamma"], gen["gamma"]) < 1e-11
+    held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
+    held = run(capi, alpha, eta, ptr, ids, cts, heldout=True, options=[("force_variant", 4)])
+    check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"],
+                  ll_key="doc_words_ll", min_same=0.95)
+    # bitwise reproducible: fixed summation order everywhere
+    again = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 4)])
+    assert np.array_equal(out["gamma"], again["gamma"]) and np.array_equal(out["sstats"], again["sstats"])
+    assert np.array_equal(out["doc_ll"], again["doc_ll"])
 
 
 def test_edge_cases_empty_ragged_and_limits(capi):
