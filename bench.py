@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ap-extra", action="store_true")
+    ap.add_argument("--variant", type=int, default=-1, help="force a kernel variant (A/B runs)")
     args = ap.parse_args()
 
     import torch
@@ -148,6 +149,8 @@ def main():
     if "alpha" in wl:
         vb._alpha_alpha = wl["alpha"].copy()
     ctx = vb._context()
+    if args.variant >= 0:
+        ctx.set_option("force_variant", args.variant)
     if group is None:
         distributed.bind_to_torch_stream(ctx)
 

@@ -21,6 +21,7 @@
 #include "estep_generic.h"
 #include "estep_logspace.h"
 #include "estep_slab.h"
+#include "estep_column.h"
 #include "mstep_kernels.h"
 #include "prepare_kernels.h"
 #include "sstats_kernels.h"
@@ -36,7 +37,8 @@ enum Variant : int {
     kGeneric256 = 1,   // 4 wavefronts / document, tile in LDS
     kGeneric512 = 2,   // 8 wavefronts / document, tile in LDS (up to the whole 160 KiB)
     kGenericGlobal = 3, // tile larger than LDS: rows re-read from the table
-    kSlab = 4           // tile in registers (estep_slab.h); RN picked per launch
+    kSlab = 4,          // tile in registers, word-major lanes (estep_slab.h)
+    kColumn = 5         // tile in registers, topic-major lanes (estep_column.h)
 };
 
 struct Launch {
@@ -182,9 +184,23 @@ SlabGeom slab_geom_for(const pylda_ctx* ctx, int n)
     return {0, 0, 0};
 }
 
+// Column (topic-major, register-resident) kernel: words per wavefront, or 0.
+int column_rnw_for(const pylda_ctx* ctx, int n)
+{
+    if (ctx->ldk != 64 && ctx->ldk != 128) return 0;
+    if (n <= 64) return 8;
+    if (n <= 128) return 16;
+    if (n <= 256) return 32;
+    return 0;
+}
+
 // Decide the kernel variant for a document with n distinct terms.
 int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
 {
+    if ((ctx->force_variant < 0 || ctx->force_variant == kColumn) && column_rnw_for(ctx, n) > 0) {
+        *lds_bytes = 0;
+        return kColumn;
+    }
     if ((ctx->force_variant < 0 || ctx->force_variant == kSlab) && slab_geom_for(ctx, n).W > 0) {
         *lds_bytes = 0;
         return kSlab;
@@ -194,7 +210,7 @@ int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
     const size_t l256 = generic_lds_layout(K, n, stride, 256, false).total;
     const size_t l512 = generic_lds_layout(K, n, stride, 512, false).total;
     int v;
-    if (ctx->force_variant >= 0 && ctx->force_variant != kSlab) v = ctx->force_variant;
+    if (ctx->force_variant >= 0 && ctx->force_variant < kSlab) v = ctx->force_variant;
     else if (l64 <= 20 * 1024) v = kGeneric64;
     else if (l256 <= 64 * 1024) v = kGeneric256;
     else if (l512 <= ctx->lds_limit) v = kGeneric512;
@@ -229,6 +245,7 @@ void build_plan(pylda_corpus* c)
             size_t lds_j;
             const int vj = choose_variant(ctx, c->h_terms_sorted[j], &lds_j);
             if (vj != v) break;
+            if (v == kColumn && column_rnw_for(ctx, c->h_terms_sorted[j]) != column_rnw_for(ctx, c->h_terms_sorted[i])) break;
             if (v == kSlab) {
                 const SlabGeom gi = slab_geom_for(ctx, c->h_terms_sorted[i]), gj = slab_geom_for(ctx, c->h_terms_sorted[j]);
                 if (gi.RK != gj.RK || gi.RN != gj.RN) break;
@@ -245,7 +262,8 @@ void build_plan(pylda_corpus* c)
         L.n_cap = std::max(1, c->h_terms_sorted[i]);
         L.tile_stride = tile_stride_for(ctx->K);
         L.lds_bytes = lds_first;
-        L.rn = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RN : 0;
+        L.rn = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RN
+             : v == kColumn ? column_rnw_for(ctx, c->h_terms_sorted[i]) : 0;
         L.rk = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RK : 0;
         c->plan.push_back(L);
         i = j;
@@ -292,6 +310,29 @@ int launch_slab_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 #undef SLAB_RN32
 #undef SLAB_CASE
     return fail(ctx, PYLDA_ERR_STATE, "no slab kernel for W=%d RK=%d RN=%d", W, L.rk, L.rn);
+}
+
+template <int W, int KR, int RNW>
+int launch_column(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    auto kern = estep_column_kernel<W, KR, RNW>;
+    const size_t lds = ColumnLds<W, KR, RNW>::total;
+    if (lds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * W), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+int launch_column_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    const int KR = ctx->ldk / 64;
+#define COL_CASE(kr_, rnw_) \
+    if (KR == kr_ && L.rn == rnw_) return launch_column<8, kr_, rnw_>(ctx, p, L);
+    COL_CASE(1, 8) COL_CASE(1, 16) COL_CASE(1, 32) COL_CASE(2, 8) COL_CASE(2, 16) COL_CASE(2, 32)
+#undef COL_CASE
+    return fail(ctx, PYLDA_ERR_STATE, "no column kernel for KR=%d RNW=%d", KR, L.rn);
 }
 
 int enqueue_prepare(pylda_ctx* ctx, bool heldout)
@@ -539,7 +580,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kSlab)
+        if (value < -1 || value > kColumn)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
@@ -773,6 +814,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kGeneric256: rc = launch_generic<256, false>(ctx, p, L); break;
             case kGeneric512: rc = launch_generic<512, false>(ctx, p, L); break;
             case kSlab: rc = launch_slab_any(ctx, p, L); break;
+            case kColumn: rc = launch_column_any(ctx, p, L); break;
             default: rc = launch_generic<256, true>(ctx, p, L); break;
             }
             if (rc != PYLDA_OK) return rc;
