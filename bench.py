@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ap-extra", action="store_true")
     ap.add_argument("--variant", type=int, default=-1, help="force a kernel variant (A/B runs)")
+    ap.add_argument("--option", action="append", default=[], help="name=value library option (A/B runs)")
     args = ap.parse_args()
 
     import torch
@@ -151,6 +152,9 @@ def main():
     ctx = vb._context()
     if args.variant >= 0:
         ctx.set_option("force_variant", args.variant)
+    for kv in args.option:
+        name, value = kv.split("=")
+        ctx.set_option(name, int(value))
     if group is None:
         distributed.bind_to_torch_stream(ctx)
 

@@ -82,6 +82,7 @@ struct pylda_ctx {
     bool have_eta = false, have_alpha = false, have_sstats = false;
     int force_logspace = 0;
     int force_variant = -1;
+    int column_waves = 8;
     int plan_epoch = 0;
 
     bool profiling = false;
@@ -185,12 +186,13 @@ SlabGeom slab_geom_for(const pylda_ctx* ctx, int n)
 }
 
 // Column (topic-major, register-resident) kernel: words per wavefront, or 0.
+// column_waves: wavefronts per document (option "column_waves", 8 or 16).
 int column_rnw_for(const pylda_ctx* ctx, int n)
 {
     if (ctx->ldk != 64 && ctx->ldk != 128) return 0;
-    if (n <= 64) return 8;
-    if (n <= 128) return 16;
-    if (n <= 256) return 32;
+    const int W = ctx->column_waves;
+    for (int rnw = 8; rnw <= (W == 16 ? 16 : 32); rnw *= 2)
+        if (n <= W * rnw) return rnw;
     return 0;
 }
 
@@ -328,9 +330,10 @@ int launch_column(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 int launch_column_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
     const int KR = ctx->ldk / 64;
-#define COL_CASE(kr_, rnw_) \
-    if (KR == kr_ && L.rn == rnw_) return launch_column<8, kr_, rnw_>(ctx, p, L);
-    COL_CASE(1, 8) COL_CASE(1, 16) COL_CASE(1, 32) COL_CASE(2, 8) COL_CASE(2, 16) COL_CASE(2, 32)
+#define COL_CASE(w_, kr_, rnw_) \
+    if (ctx->column_waves == w_ && KR == kr_ && L.rn == rnw_) return launch_column<w_, kr_, rnw_>(ctx, p, L);
+    COL_CASE(8, 1, 8) COL_CASE(8, 1, 16) COL_CASE(8, 1, 32) COL_CASE(8, 2, 8) COL_CASE(8, 2, 16) COL_CASE(8, 2, 32)
+    COL_CASE(16, 1, 8) COL_CASE(16, 1, 16) COL_CASE(16, 2, 8) COL_CASE(16, 2, 16)
 #undef COL_CASE
     return fail(ctx, PYLDA_ERR_STATE, "no column kernel for KR=%d RNW=%d", KR, L.rn);
 }
@@ -583,6 +586,10 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         if (value < -1 || value > kColumn)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
+        ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "column_waves")) {
+        if (value != 8 && value != 16) return fail(ctx, PYLDA_ERR_INVALID, "column_waves must be 8 or 16");
+        ctx->column_waves = (int)value;
         ctx->plan_epoch += 1;
     } else
         return fail(ctx, PYLDA_ERR_INVALID, "unknown option '%s'", name);

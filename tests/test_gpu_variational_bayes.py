@@ -50,6 +50,31 @@ def test_learning_trace_matches_reference(ap_model, ap_train):
     assert m._counter == n
 
 
+def test_hundred_iteration_trace_and_heldout(ap_train, ap_test):
+    """BASELINE.json cfg 1/2 end to end: 100 learning() iterations on AP K=10 from the reference's
+    seeded initial state reproduce its joint log-likelihood and alpha traces, then its held-out
+    words log-likelihood (launch_train + launch_test flow)."""
+    from pylda_amd.variational_bayes import VariationalBayes
+    tr = load_golden("ap_trace_k10.npz")
+    if len(tr["joint_ll"]) < 100:
+        pytest.skip("short trace fixture")
+    g = ap_train
+    words = [str(w) for w in g["words"]]
+    docs = documents_from_csr(words, g["doc_ptr"], g["term_id"], g["term_ct"])
+    np.random.seed(int(tr["seed"]))
+    m = VariationalBayes()
+    m._verbose = False
+    m._initialize(docs, words, 10, 1.0 / 10, 1.0 / len(words))
+    joint = np.array([m.learning() for _ in range(100)])
+    assert rel_err(joint, tr["joint_ll"]) < 1e-7
+    assert rel_err(m._alpha_alpha, tr["alpha"][-1]) < 1e-6
+    h = ap_test
+    test_docs = documents_from_csr(words, h["doc_ptr"], h["term_id"], h["term_ct"])
+    wll, gamma = m.inference(test_docs)
+    assert abs(wll - float(tr["heldout_words_ll_end"])) < 1e-7 * abs(float(tr["heldout_words_ll_end"]))
+    assert gamma.shape == (221, 10)
+
+
 def test_e_step_m_step_contract(ap_model, ap_train):
     """Public e_step()/m_step() keep the reference's host-array contract (:212-216, :218-235)."""
     from pylda_amd.variational_bayes import VariationalBayes
