@@ -22,6 +22,7 @@
 #include "estep_logspace.h"
 #include "estep_slab.h"
 #include "estep_column.h"
+#include "estep_quilt.h"
 #include "mstep_kernels.h"
 #include "prepare_kernels.h"
 #include "sstats_kernels.h"
@@ -38,7 +39,8 @@ enum Variant : int {
     kGeneric512 = 2,   // 8 wavefronts / document, tile in LDS (up to the whole 160 KiB)
     kGenericGlobal = 3, // tile larger than LDS: rows re-read from the table
     kSlab = 4,          // tile in registers, word-major lanes (estep_slab.h)
-    kColumn = 5         // tile in registers, topic-major lanes (estep_column.h)
+    kColumn = 5,        // tile in registers, topic-major lanes (estep_column.h)
+    kQuilt = 6          // tile in registers, 4 x 16 word-group x topic lanes (estep_quilt.h)
 };
 
 struct Launch {
@@ -196,9 +198,23 @@ int column_rnw_for(const pylda_ctx* ctx, int n)
     return 0;
 }
 
+// Quilt (2-D lanes, register-resident) kernel: words per lane, or 0.
+int quilt_rwl_for(const pylda_ctx* ctx, int n)
+{
+    if (ctx->ldk != 64 && ctx->ldk != 128) return 0;
+    if (n <= 64) return 2;
+    if (n <= 128) return 4;
+    if (n <= 256) return 8;
+    return 0;
+}
+
 // Decide the kernel variant for a document with n distinct terms.
 int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
 {
+    if ((ctx->force_variant < 0 || ctx->force_variant == kQuilt) && quilt_rwl_for(ctx, n) > 0) {
+        *lds_bytes = 0;
+        return kQuilt;
+    }
     if ((ctx->force_variant < 0 || ctx->force_variant == kColumn) && column_rnw_for(ctx, n) > 0) {
         *lds_bytes = 0;
         return kColumn;
@@ -247,6 +263,7 @@ void build_plan(pylda_corpus* c)
             size_t lds_j;
             const int vj = choose_variant(ctx, c->h_terms_sorted[j], &lds_j);
             if (vj != v) break;
+            if (v == kQuilt && quilt_rwl_for(ctx, c->h_terms_sorted[j]) != quilt_rwl_for(ctx, c->h_terms_sorted[i])) break;
             if (v == kColumn && column_rnw_for(ctx, c->h_terms_sorted[j]) != column_rnw_for(ctx, c->h_terms_sorted[i])) break;
             if (v == kSlab) {
                 const SlabGeom gi = slab_geom_for(ctx, c->h_terms_sorted[i]), gj = slab_geom_for(ctx, c->h_terms_sorted[j]);
@@ -265,7 +282,8 @@ void build_plan(pylda_corpus* c)
         L.tile_stride = tile_stride_for(ctx->K);
         L.lds_bytes = lds_first;
         L.rn = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RN
-             : v == kColumn ? column_rnw_for(ctx, c->h_terms_sorted[i]) : 0;
+             : v == kColumn ? column_rnw_for(ctx, c->h_terms_sorted[i])
+             : v == kQuilt ? quilt_rwl_for(ctx, c->h_terms_sorted[i]) : 0;
         L.rk = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RK : 0;
         c->plan.push_back(L);
         i = j;
@@ -336,6 +354,29 @@ int launch_column_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     COL_CASE(16, 1, 8) COL_CASE(16, 1, 16) COL_CASE(16, 2, 8) COL_CASE(16, 2, 16)
 #undef COL_CASE
     return fail(ctx, PYLDA_ERR_STATE, "no column kernel for KR=%d RNW=%d", KR, L.rn);
+}
+
+template <int W, int KRL, int RWL>
+int launch_quilt(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    auto kern = estep_quilt_kernel<W, KRL, RWL>;
+    const size_t lds = QuiltLds<W, KRL, RWL>::total;
+    if (lds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * W), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+int launch_quilt_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    const int KRL = ctx->ldk / 16;
+#define QUILT_CASE(krl_, rwl_) \
+    if (KRL == krl_ && L.rn == rwl_) return launch_quilt<8, krl_, rwl_>(ctx, p, L);
+    QUILT_CASE(4, 2) QUILT_CASE(4, 4) QUILT_CASE(4, 8) QUILT_CASE(8, 2) QUILT_CASE(8, 4) QUILT_CASE(8, 8)
+#undef QUILT_CASE
+    return fail(ctx, PYLDA_ERR_STATE, "no quilt kernel for KRL=%d RWL=%d", KRL, L.rn);
 }
 
 int enqueue_prepare(pylda_ctx* ctx, bool heldout)
@@ -583,7 +624,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kColumn)
+        if (value < -1 || value > kQuilt)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
@@ -822,6 +863,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kGeneric512: rc = launch_generic<512, false>(ctx, p, L); break;
             case kSlab: rc = launch_slab_any(ctx, p, L); break;
             case kColumn: rc = launch_column_any(ctx, p, L); break;
+            case kQuilt: rc = launch_quilt_any(ctx, p, L); break;
             default: rc = launch_generic<256, true>(ctx, p, L); break;
             }
             if (rc != PYLDA_OK) return rc;

@@ -1,0 +1,299 @@
+// Register-resident E-step kernel, 2-D ("quilt") lane layout, for 32 < K <= 128.
+//
+// One workgroup = one document = W wavefronts; the N_d x K tile of
+// B = exp(E_log_eta - shift) lives in VGPRs.  Within a wavefront the 64 lanes
+// form a 4 x 16 grid:
+//   lane = 16*g + c :  word group g (0..3)  x  topic lane c (0..15)
+//   lane owns words   nb + g*RWL + i   (i < RWL)        (nb = first word of the wave)
+//        and topics   c + 16*j         (j < KRL = ldk/16)
+//   => registers B[RWL][KRL]; a table row is read as 16-lane x 128-byte pieces.
+//
+// Why 2-D: each inner iteration needs two reductions across lanes,
+//   nrm[n] = sum_k B[n][k] t[k]   (over topic lanes)   and
+//   s[k]   = sum_n r[n] B[n][k]   (over word groups, then over wavefronts),
+// and the cost of a cross-lane reduction is proportional to the number of values
+// each lane carries into it.  The column kernel (estep_column.h) carried 32
+// normaliser partials per lane through two permlane-swap levels (100 of its 260
+// VALU instructions per wave-iteration); here the normalisers need only a 16-lane
+// sum (one LDS transpose, no swaps) and the topic sums enter the swap levels with
+// KRL = 8 values instead of 32.
+//
+// Iteration structure, barriers and the gamma phase are those of the column kernel.
+#pragma once
+#include "estep_common.h"
+#include "estep_slab.h"        // swap32_add / swap16_add / fast_rcp
+#include "special_device.h"
+
+namespace pylda {
+
+template <int W, int KRL, int RWL>
+struct QuiltLds {
+    static constexpr int kTopics = 16 * KRL;
+    static constexpr int kWordsPerWave = 4 * RWL;
+    static constexpr size_t red = 0;                                               // [W][4*RWL][17]
+    static constexpr size_t rr = red + (size_t)W * kWordsPerWave * 17 * 8;         // [W][4*RWL]
+    static constexpr size_t sp = rr + (size_t)W * kWordsPerWave * 8;               // [W][kTopics]
+    static constexpr size_t tt = sp + (size_t)W * kTopics * 8;                     // [2][kTopics]
+    static constexpr size_t chg = tt + (size_t)2 * kTopics * 8;                    // u64[2]
+    static constexpr size_t misc = chg + 16;                                       // [8][W]
+    static constexpr size_t total = (misc + (size_t)8 * W * 8 + 15) & ~(size_t)15;
+};
+
+template <int W, int KRL, int RWL>
+__global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
+{
+    using L = QuiltLds<W, KRL, RWL>;
+    constexpr int NT = kWave * W;
+    constexpr int KT = 16 * KRL;            // padded topic count (== ldk)
+    constexpr int RNW = 4 * RWL;            // words per wavefront
+    constexpr int LPW = kWave / RNW;        // lanes that finish one word's normaliser
+    constexpr int PER = 16 / LPW;           // partials each of them adds
+    constexpr int QV = KRL / 4;             // topic values per lane after the swap levels
+    static_assert(KRL == 4 || KRL == 8, "ldk 64 or 128");
+    static_assert(RWL == 2 || RWL == 4 || RWL == 8, "words per lane");
+    static_assert(KT <= NT, "one thread per topic in the gamma phase");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem + L::red);
+    double* rr = reinterpret_cast<double*>(smem + L::rr);
+    double* sp = reinterpret_cast<double*>(smem + L::sp);
+    double* tt = reinterpret_cast<double*>(smem + L::tt);
+    unsigned long long* chg = reinterpret_cast<unsigned long long*>(smem + L::chg);
+    double* misc = reinterpret_cast<double*>(smem + L::misc);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int g = lane >> 4, c = lane & 15;
+    const int K = p.K, ldk = p.ldk;
+    const int doc = p.order[blockIdx.x];
+    const int64_t lo = p.doc_ptr[doc];
+    const int N = (int)(p.doc_ptr[doc + 1] - lo);
+    const int nb = wave * RNW;
+    const int wb = nb + g * RWL;            // first word of this lane
+
+    // ---- load the tile ----
+    double B[RWL][KRL];
+#pragma unroll
+    for (int i = 0; i < RWL; ++i) {
+        const int n = wb + i;
+        if (n < N) {
+            const double* row = p.expElog + (size_t)p.term_id[lo + n] * ldk + c;
+#pragma unroll
+            for (int j = 0; j < KRL; ++j) B[i][j] = row[16 * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < KRL; ++j) B[i][j] = 0.0;
+        }
+    }
+    // the word whose normaliser this lane finishes: nb + lane / LPW
+    const int my_word = nb + lane / LPW;
+    const bool word_live = my_word < N;
+    const double my_cnt = word_live ? (double)p.term_ct[lo + my_word] : 0.0;
+
+    // ---- total token count (:162) and the invariant sum_k gamma_k ----
+    double local = 0.0;
+    for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
+    local = wave_sum(local);
+    double asum = 0.0;
+    for (int k = lane; k < K; k += kWave) asum += p.alpha[k];
+    asum = wave_sum(asum);
+    if (lane == 0) misc[wave] = local;
+    if (tid == 0) chg[0] = chg[1] = 0ull;
+    __syncthreads();
+    double total = 0.0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) total += misc[w];
+    const double psi_total = digamma(asum + total);
+
+    // ---- gamma phase state: thread k < KT owns topic k ----
+    const bool topic_thread = tid < KT;
+    const bool topic_live = tid < K;
+    const double alpha_k = topic_live ? p.alpha[tid] : 1.0;
+    double gam = alpha_k + total / K;                                     // :165
+    double gam_prev = gam;
+    double t_mine = 0.0;
+    if (topic_thread) {
+        t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
+        tt[tid] = t_mine;
+    }
+    __syncthreads();
+
+    double r_mine = 0.0, nrm_mine = 1.0;
+    int it = 0;
+    int bad = 0;
+    double* myred = red + (size_t)wave * RNW * 17;
+    double* myrr = rr + wave * RNW;
+    while (it < p.max_iter) {                                             // :174
+        const int buf = it & 1;
+        double tq[KRL];
+#pragma unroll
+        for (int j = 0; j < KRL; ++j) tq[j] = tt[buf * KT + c + 16 * j];
+
+        // A. partial normalisers over this lane's topics -> LDS transpose -> sum over the 16 topic lanes
+#pragma unroll
+        for (int i = 0; i < RWL; ++i) {
+            double a0 = B[i][0] * tq[0], a1 = B[i][1] * tq[1];
+#pragma unroll
+            for (int j = 2; j < KRL; j += 2) {
+                a0 = fma(B[i][j], tq[j], a0);
+                a1 = fma(B[i][j + 1], tq[j + 1], a1);
+            }
+            myred[(g * RWL + i) * 17 + c] = a0 + a1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        {
+            const int part = lane % LPW;
+            const double* src = myred + (lane / LPW) * 17 + part * PER;
+            double s0 = src[0], s1 = PER > 1 ? src[1] : 0.0;
+#pragma unroll
+            for (int x = 2; x < PER; x += 2) {
+                s0 += src[x];
+                s1 += src[x + 1];
+            }
+            double s = s0 + s1;
+#pragma unroll
+            for (int m = 1; m < LPW; m <<= 1) s += __shfl_xor(s, m, kWave);
+            nrm_mine = s;
+            if (word_live && !(s > 1e-280 && s < 1e300)) bad = 1;
+            r_mine = word_live ? my_cnt * fast_rcp(s) : 0.0;
+            if (part == 0) myrr[lane / LPW] = r_mine;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        // B. q[k] over this lane's words, then over the 4 word groups (two swap levels)
+        double q[KRL];
+        {
+            const double2* rsrc = reinterpret_cast<const double2*>(myrr + g * RWL);
+            const double2 r01 = rsrc[0];
+#pragma unroll
+            for (int j = 0; j < KRL; ++j) q[j] = fma(r01.y, B[1][j], r01.x * B[0][j]);
+#pragma unroll
+            for (int i = 2; i < RWL; i += 2) {
+                const double2 r2 = rsrc[i / 2];
+#pragma unroll
+                for (int j = 0; j < KRL; ++j) q[j] = fma(r2.y, B[i + 1][j], fma(r2.x, B[i][j], q[j]));
+            }
+        }
+        double u[KRL / 2];
+#pragma unroll
+        for (int m = 0; m < KRL / 2; ++m) u[m] = swap32_add(q[m], q[m + KRL / 2]);
+        // lane (row g, column c) now holds, for m < QV, topic slot m + (g&1)*QV + (g>>1)*KRL/2
+#pragma unroll
+        for (int m = 0; m < QV; ++m) {
+            const double v = swap16_add(u[m], u[m + QV]);
+            const int slot = m + (g & 1) * QV + (g >> 1) * (KRL / 2);
+            sp[wave * KT + c + 16 * slot] = v;
+        }
+        __syncthreads();
+
+        // C. gamma update by the topic threads
+        if (topic_thread) {
+            double s0 = sp[tid], s1 = sp[KT + tid];
+#pragma unroll
+            for (int w = 2; w < W; w += 2) {
+                s0 += sp[w * KT + tid];
+                s1 += sp[(w + 1) * KT + tid];
+            }
+            const double gnew = fma(t_mine, s0 + s1, alpha_k);            // :185
+            const double diff = topic_live ? fabs(gnew - gam) : 0.0;      // :187
+            gam_prev = gam;
+            gam = gnew;                                                   // :188
+            const double clipped = fmin(diff, 1024.0) * kChangeScale;
+            atomicAdd(&chg[buf], (unsigned long long)(clipped + 0.5));
+            t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
+            tt[(buf ^ 1) * KT + tid] = t_mine;
+            if (tid == 0) chg[buf ^ 1] = 0ull;
+        }
+        ++it;
+        __syncthreads();
+        const double change = (double)chg[buf] * (1.0 / kChangeScale);
+        if (change <= p.tol * K) break;                                   // :189 (mean <= tol)
+    }
+    const int last = (it - 1) & 1;          // tt[last] holds t of the last executed iteration
+
+    bad = __syncthreads_or(bad);
+    if (bad) {
+        if (!p.heldout) {      // contributes nothing to the gather pass; the log-space kernel adds it
+            for (int n = tid; n < N; n += NT) p.rfinal[lo + n] = 0.0;
+            for (int k = tid; k < ldk; k += NT) p.tfinal[(size_t)doc * ldk + k] = 0.0;
+        }
+        if (tid == 0) p.status[doc] = 1;
+        return;
+    }
+
+    // ---- document terms (:195-204) with the last phi = B t r (see estep_slab.h) ----
+    double tq[KRL];
+#pragma unroll
+    for (int j = 0; j < KRL; ++j) tq[j] = tt[last * KT + c + 16 * j];
+    double term1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < RWL; ++i) {
+        const int n = wb + i;
+        if (n < N) {
+            const double* row = p.expElog_elog + (size_t)p.term_id[lo + n] * ldk + c;
+            double gsum2 = row[0] * tq[0];
+#pragma unroll
+            for (int j = 1; j < KRL; ++j) gsum2 = fma(row[16 * j], tq[j], gsum2);
+            term1 = fma(myrr[g * RWL + i], gsum2, term1);
+        }
+    }
+    const bool word_owner = word_live && (lane % LPW) == 0;
+    double term3 = word_owner ? my_cnt * log(nrm_mine) : 0.0;
+    double shift_term = (word_owner && p.heldout) ? my_cnt * p.shift[p.term_id[lo + my_word]] : 0.0;
+    double term2 = 0.0, lse_term = 0.0, lgam = 0.0, gsum = 0.0;
+    if (topic_live) {
+        const double t_last = tt[last * KT + tid];
+        const double moved = gam - alpha_k;                               // = t_last * s
+        const double ltv = digamma(gam_prev) - psi_total;                 // log t of the last iteration
+        term2 = ltv * moved;
+        if (p.heldout) lse_term = p.topic_lse[tid] * moved;
+        lgam = lgamma_pos(gam);
+        gsum = gam;
+        p.gamma[(size_t)doc * K + tid] = gam;
+        if (!p.heldout) p.tfinal[(size_t)doc * ldk + tid] = t_last;
+    } else if (topic_thread && !p.heldout) {
+        p.tfinal[(size_t)doc * ldk + tid] = 0.0;
+    }
+    if (word_owner && !p.heldout) p.rfinal[lo + my_word] = r_mine;
+    term1 = wave_sum(term1);
+    term2 = wave_sum(term2);
+    lse_term = wave_sum(lse_term);
+    lgam = wave_sum(lgam);
+    gsum = wave_sum(gsum);
+    term3 = wave_sum(term3);
+    shift_term = wave_sum(shift_term);
+    if (lane == 0) {
+        misc[0 * W + wave] = term1;
+        misc[1 * W + wave] = term2;
+        misc[2 * W + wave] = lse_term;
+        misc[3 * W + wave] = lgam;
+        misc[4 * W + wave] = gsum;
+        misc[5 * W + wave] = term3;
+        misc[6 * W + wave] = shift_term;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t1 = 0.0, t2 = 0.0, tl = 0.0, lg = 0.0, gs = 0.0, t3 = 0.0, sh = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            t1 += misc[0 * W + w];
+            t2 += misc[1 * W + w];
+            tl += misc[2 * W + w];
+            lg += misc[3 * W + w];
+            gs += misc[4 * W + w];
+            t3 += misc[5 * W + w];
+            sh += misc[6 * W + w];
+        }
+        const double ent = t1 + t2 - t3;
+        p.doc_ll[doc] = p.alpha_term + lg - lgamma_pos(gs) - ent;        // :195-199
+        p.doc_words_ll[doc] = p.heldout ? t1 + sh - tl : 0.0;            // :204
+        p.iters[doc] = it;
+        p.status[doc] = 0;
+    }
+}
+
+}  // namespace pylda

@@ -93,7 +93,7 @@ def test_ap_heldout_k10_matches_reference_goldens(capi, ap_test):
     assert abs(out["words_log_likelihood"] - float(g["corpus_words_ll"])) < 1e-9 * abs(float(g["corpus_words_ll"]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 def test_every_kernel_variant_agrees(capi, ap_train, variant):
     g = ap_train
     docs = list(range(0, 2000, 10))
@@ -193,7 +193,7 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
     ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
     gen = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 1)])
     held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
-    for variant in (4, 5):                       # slab (word-major lanes), column (topic-major lanes)
+    for variant in (4, 5, 6):                    # slab (word-major), column (topic-major), quilt (2-D lanes)
         out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
         check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
         assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
