@@ -158,6 +158,9 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value);
 int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digamma_out,
                        double* lgamma_out);
 
+/* Test hook: out[i] = exp(digamma(x[i]) - c), the fused form the inner loop uses. */
+int pylda_test_expdigamma(pylda_ctx* ctx, int64_t n, const double* x, double c, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,7 @@ SIGNATURES = {
     "pylda_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pylda_kernel_time": (ctypes.c_int, [_vp, _c_double_p, _c_int64_p]),
     "pylda_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+    "pylda_test_expdigamma": (ctypes.c_int, [_vp, ctypes.c_int64, _c_double_p, ctypes.c_double, _c_double_p]),
     "pylda_test_special": (ctypes.c_int, [_vp, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p]),
 }
 
@@ -238,6 +239,12 @@ class Context(object):
         ms, calls = ctypes.c_double(0), ctypes.c_int64(0)
         self._check(self._lib.pylda_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(calls)))
         return ms.value, calls.value
+
+    def test_expdigamma(self, x, c):
+        x = _f64(x)
+        out = np.empty_like(x)
+        self._check(self._lib.pylda_test_expdigamma(self._h, x.size, _dp(x), float(c), _dp(out)))
+        return out
 
     def test_special(self, x):
         x = _f64(x)

@@ -1092,6 +1092,11 @@ __global__ void special_test_kernel(const double* x, int64_t n, double* dg, doub
         lg[i] = pylda::lgamma_pos(x[i]);
     }
 }
+__global__ void expdigamma_test_kernel(const double* x, int64_t n, double c, double* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pylda::exp_digamma_minus(x[i], c);
+}
 }  // namespace
 
 int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digamma_out, double* lgamma_out)
@@ -1115,6 +1120,28 @@ int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digam
         if (e != hipSuccess) rc = fail(ctx, PYLDA_ERR_HIP, "test_special: %s", hipGetErrorString(e));
     }
     dev_free(dx); dev_free(dd); dev_free(dl);
+    return rc;
+}
+
+int pylda_test_expdigamma(pylda_ctx* ctx, int64_t n, const double* x, double c, double* out)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (n < 0 || !x || !out) return fail(ctx, PYLDA_ERR_INVALID, "test_expdigamma: bad argument");
+    if (n == 0) return PYLDA_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double *dx = nullptr, *dout = nullptr;
+    int rc = dev_alloc(ctx, &dx, (size_t)n);
+    if (rc == PYLDA_OK) rc = dev_alloc(ctx, &dout, (size_t)n);
+    if (rc == PYLDA_OK) {
+        hipError_t e = hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(expdigamma_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dx, n, c, dout);
+            e = hipStreamSynchronize(ctx->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, PYLDA_ERR_HIP, "test_expdigamma: %s", hipGetErrorString(e));
+    }
+    dev_free(dx); dev_free(dout);
     return rc;
 }
 

@@ -63,16 +63,7 @@ __device__ __forceinline__ double swap16_add(double a, double b)
     return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
 
-// 1/x for normal positive x: v_rcp_f64 seed + two Newton steps (the same
-// refinement the compiler's IEEE division uses, without the scaling fix-ups).
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double y = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-x, y, 1.0);
-    return fma(y, e, y);
-}
+__device__ __forceinline__ double fast_rcp(double x) { return rcp_newton(x); }
 
 template <int W, int RK, int RN>
 __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)

@@ -57,6 +57,21 @@ def test_device_special_functions(capi):
     assert np.max(np.abs(lg - g["gammaln"]) / np.maximum(1.0, np.abs(g["gammaln"]))) < 5e-14
 
 
+def test_device_fused_exp_digamma(capi):
+    """t[k] = exp(psi(gamma_k) - c): the fused, log-free form against scipy over the range gamma takes."""
+    g = load_golden("special_fn.npz")
+    x = g["x"][(g["x"] > 1e-4) & (g["x"] < 1e5)]
+    ctx = capi.Context(2, 2)
+    for c in (0.0, 3.5, -1.25, 9.0):
+        got = ctx.test_expdigamma(x, c)
+        want = np.exp(g["psi"][(g["x"] > 1e-4) & (g["x"] < 1e5)] - c)
+        ok = want > 1e-290
+        psi = g["psi"][(g["x"] > 1e-4) & (g["x"] < 1e5)]
+        # the exponent psi - c carries ~1 ulp of ITS magnitude: |psi| ~ 1e3 at x ~ 1e-3 costs 3 digits
+        assert np.all(np.abs(got[ok] - want[ok]) / want[ok] < 2e-15 * (4.0 + np.abs(psi[ok] - c)))
+    ctx.close()
+
+
 def test_tiny_training_and_heldout(capi, tiny):
     t = tiny
     out = run(capi, t["alpha"], t["eta"], t["doc_ptr"], t["term_id"], t["term_ct"])
