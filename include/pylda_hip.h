@@ -149,6 +149,11 @@ int pylda_set_profiling(pylda_ctx* ctx, int enabled);
 int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, int64_t* estep_calls);
 
 /* Tuning / test options:
+ *   "doc_values"     1 (default): pylda_get_doc_values returns complete per-document
+ *                    log-likelihoods.  0: training fast path - the corpus-level
+ *                    document_log_likelihood is identical, but its log-B entropy term is
+ *                    taken once per corpus from the sufficient statistics instead of a
+ *                    second table gather per document; doc_ll[] is then unavailable;
  *   "force_logspace" 0|1  run every document through the log-space
  *                         safety-net kernel (the reference's formulation);
  *   "force_variant"  -1 (automatic) or a kernel variant index. */

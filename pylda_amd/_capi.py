@@ -203,6 +203,7 @@ class Context(object):
         wll = np.empty(corpus.D) if want_doc_values else None
         iters = np.empty(corpus.D, dtype=np.int32) if want_doc_values else None
         scal = np.zeros(2)
+        self.set_option("doc_values", 1 if want_doc_values else 0)
         self._check(self._lib.pylda_estep_host(
             self._h, corpus._h, _dp(alpha), _dp(eta), int(max_iter), float(tol),
             1 if heldout else 0, _dp(gamma), _dp(sstats), _dp(ll), _dp(wll), _ip(iters), _dp(scal)))

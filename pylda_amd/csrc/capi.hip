@@ -85,6 +85,7 @@ struct pylda_ctx {
     int force_logspace = 0;
     int force_variant = -1;
     int column_waves = 8;
+    int doc_values = 1;             // 1: per-document log-likelihoods complete (see EstepParams::want_doc_ll)
     int plan_epoch = 0;
 
     bool profiling = false;
@@ -110,7 +111,9 @@ struct pylda_corpus {
     int32_t* d_iters = nullptr;
     int32_t* d_status = nullptr;
     int32_t* d_flag_list = nullptr;
-    double* d_scalars = nullptr;   // [0] doc ll, [1] words ll
+    double* d_scalars = nullptr;   // [0] doc ll, [1] words ll, [2] corpus entropy term (fast path)
+    double* d_entropy_partial = nullptr;
+    bool last_doc_values = true;
     double* d_tfinal = nullptr;    // D x ldk
     double* d_rfinal = nullptr;    // nnz
     // postings (CSC) of the corpus for the sufficient-statistics gather pass
@@ -469,8 +472,12 @@ int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
                                c->d_rfinal, ldk, c->d_partial);
     }
     const int64_t total = (int64_t)ctx->V * ldk;
-    hipLaunchKernelGGL(sstats_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       c->d_word_seg_ptr, c->d_partial, ctx->d_expElog, ctx->V, ldk, ctx->d_sstats);
+    const unsigned fblocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(sstats_finalize_kernel, dim3(fblocks), dim3(256), 0, ctx->stream,
+                       c->d_word_seg_ptr, c->d_partial, ctx->d_expElog, ctx->d_expElog_elog, ctx->V, ldk,
+                       ctx->d_sstats, c->d_entropy_partial);
+    hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_entropy_partial,
+                       (int64_t)fblocks, c->d_scalars + 2);
     HIP_TRY(ctx, hipGetLastError());
     return PYLDA_OK;
 }
@@ -628,6 +635,8 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "doc_values")) {
+        ctx->doc_values = value != 0;
     } else if (!strcmp(name, "column_waves")) {
         if (value != 8 && value != 16) return fail(ctx, PYLDA_ERR_INVALID, "column_waves must be 8 or 16");
         ctx->column_waves = (int)value;
@@ -702,6 +711,7 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
     A(dev_alloc(ctx, &c->d_status, (size_t)D));
     A(dev_alloc(ctx, &c->d_flag_list, (size_t)D));
     A(dev_alloc(ctx, &c->d_scalars, (size_t)4));
+    A(dev_alloc(ctx, &c->d_entropy_partial, (size_t)(((int64_t)ctx->V * ctx->ldk + 255) / 256)));
     A(dev_alloc(ctx, &c->d_tfinal, (size_t)D * ctx->ldk));
     A(dev_alloc(ctx, &c->d_rfinal, (size_t)nnz));
     if (rc != PYLDA_OK) {
@@ -736,7 +746,7 @@ void pylda_corpus_destroy(pylda_corpus* c)
     }
     dev_free(c->d_doc_ptr); dev_free(c->d_term_id); dev_free(c->d_term_ct); dev_free(c->d_order);
     dev_free(c->d_gamma); dev_free(c->d_doc_ll); dev_free(c->d_doc_wll); dev_free(c->d_iters);
-    dev_free(c->d_status); dev_free(c->d_flag_list); dev_free(c->d_scalars);
+    dev_free(c->d_status); dev_free(c->d_flag_list); dev_free(c->d_scalars); dev_free(c->d_entropy_partial);
     dev_free(c->d_tfinal); dev_free(c->d_rfinal); dev_free(c->d_post_doc); dev_free(c->d_post_pos);
     dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial);
     delete c;
@@ -831,6 +841,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     p.max_iter = max_iter;
     p.tol = tol;
     p.heldout = heldout;
+    p.want_doc_ll = (heldout || ctx->doc_values) ? 1 : 0;
     p.gamma = c->d_gamma;
     p.doc_ll = c->d_doc_ll;
     p.doc_words_ll = c->d_doc_wll;
@@ -899,6 +910,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     HIP_TRY(ctx, hipGetLastError());
     c->estep_done = true;
     c->last_heldout = heldout;
+    c->last_doc_values = p.want_doc_ll != 0;
     if (!heldout) ctx->have_sstats = true;
     return PYLDA_OK;
 }
@@ -910,11 +922,13 @@ int pylda_estep_results(pylda_ctx* ctx, pylda_corpus* c, double* document_log_li
     if (!c || c->ctx != ctx) return fail(ctx, PYLDA_ERR_INVALID, "estep_results: bad corpus");
     if (!c->estep_done) return fail(ctx, PYLDA_ERR_STATE, "estep_results: no E-step has run on this corpus");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    double sc[2] = {0, 0};
+    double sc[3] = {0, 0, 0};
     int32_t nflag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(sc, c->d_scalars, sizeof sc, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(&nflag, ctx->d_flag_count, sizeof nflag, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // training fast path: the log B entropy term comes once per corpus from the statistics
+    if (!c->last_doc_values) sc[0] -= sc[2];
     if (document_log_likelihood) *document_log_likelihood = sc[0];
     if (words_log_likelihood) *words_log_likelihood = sc[1];
     if (logspace_documents) *logspace_documents = nflag;
@@ -974,6 +988,8 @@ int pylda_get_doc_values(pylda_ctx* ctx, pylda_corpus* c, double* doc_ll, double
     if (!ctx) return PYLDA_ERR_INVALID;
     if (!c || c->ctx != ctx) return fail(ctx, PYLDA_ERR_INVALID, "get_doc_values: bad corpus");
     if (!c->estep_done) return fail(ctx, PYLDA_ERR_STATE, "get_doc_values: no E-step has run on this corpus");
+    if (doc_ll && !c->last_doc_values)
+        return fail(ctx, PYLDA_ERR_STATE, "get_doc_values: the last E-step ran with option doc_values=0 (corpus-level likelihood only)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (doc_ll)
         HIP_TRY(ctx, hipMemcpyAsync(doc_ll, c->d_doc_ll, (size_t)c->D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -228,10 +228,11 @@ __global__ __launch_bounds__(kWave* W) void estep_column_kernel(EstepParams p)
 #pragma unroll
     for (int j = 0; j < KR; ++j) tq[j] = tt[last * KT + lane + kWave * j];
     double term1 = 0.0;
+    const bool do_term1 = p.heldout || p.want_doc_ll;     // else: taken per corpus from the statistics
 #pragma unroll
     for (int i = 0; i < RNW; ++i) {
         const int n = nb + i;
-        if (n < N) {
+        if (n < N && do_term1) {
             const double* row = p.expElog_elog + (size_t)p.term_id[lo + n] * ldk;
             double g = row[lane] * tq[0];
 #pragma unroll

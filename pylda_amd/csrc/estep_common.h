@@ -27,6 +27,9 @@ struct EstepParams {
     int max_iter;             // local_parameter_iteration            (:132)
     double tol;               // local_parameter_converge_threshold   (:132)
     int heldout;              // 1: parsed_corpus given               (:133-138)
+    int want_doc_ll;          // 1: doc_ll[] holds every term of :195-199.  0 (training fast path): the
+                              //    sum_n c_n sum_k phi log B term is left out of doc_ll[] and taken once
+                              //    per corpus from the sufficient statistics (sstats_finalize_kernel)
     double* gamma;            // D x K out                            (:188,:213)
     double* doc_ll;           // D out: this document's terms of :195-199
     double* doc_words_ll;     // D out: this document's term of :204

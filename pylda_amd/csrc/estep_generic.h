@@ -197,9 +197,10 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
         for (int kk = kl; kk < K; kk += KL) {
             const double bv = b[kk];
             const double pc = bv * t[kk] * rn;             // phi * count
-            if (bv > 0.0) {
+            ent = fma(pc, lt[kk] - ln, ent);               // :199 without the log B part
+            if (bv > 0.0 && (p.heldout || p.want_doc_ll)) {
                 const double lb = log(bv);
-                ent = fma(pc, lb + lt[kk] - ln, ent);      // :199
+                ent = fma(pc, lb, ent);                    // :199, log B part
                 if (p.heldout) wll = fma(pc, lb + sh - p.topic_lse[kk], wll);   // :204
             }
         }

@@ -5,8 +5,10 @@
 // form a 4 x 16 grid:
 //   lane = 16*g + c :  word group g (0..3)  x  topic lane c (0..15)
 //   lane owns words   nb + g*RWL + i   (i < RWL)        (nb = first word of the wave)
-//        and topics   c + 16*j         (j < KRL = ldk/16)
-//   => registers B[RWL][KRL]; a table row is read as 16-lane x 128-byte pieces.
+//        and topics   2c + 32*jj + {0,1}   (jj < KRL/2; KRL = ldk/16 topics per lane)
+//   => registers B[RWL][KRL]; a table row is read with 16-byte loads as
+//      16-lane x 256-byte contiguous pieces (8-byte global loads run at 0.5-0.7x
+//      the 16-byte rate on this part, and the tile gather is per-CU bandwidth bound).
 //
 // Why 2-D: each inner iteration needs two reductions across lanes,
 //   nrm[n] = sum_k B[n][k] t[k]   (over topic lanes)   and
@@ -77,9 +79,13 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     for (int i = 0; i < RWL; ++i) {
         const int n = wb + i;
         if (n < N) {
-            const double* row = p.expElog + (size_t)p.term_id[lo + n] * ldk + c;
+            const double2* row = reinterpret_cast<const double2*>(p.expElog + (size_t)p.term_id[lo + n] * ldk) + c;
 #pragma unroll
-            for (int j = 0; j < KRL; ++j) B[i][j] = row[16 * j];
+            for (int jj = 0; jj < KRL / 2; ++jj) {
+                const double2 v2 = row[16 * jj];
+                B[i][2 * jj] = v2.x;
+                B[i][2 * jj + 1] = v2.y;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < KRL; ++j) B[i][j] = 0.0;
@@ -127,7 +133,11 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
         const int buf = it & 1;
         double tq[KRL];
 #pragma unroll
-        for (int j = 0; j < KRL; ++j) tq[j] = tt[buf * KT + c + 16 * j];
+        for (int jj = 0; jj < KRL / 2; ++jj) {
+            const double2 t2 = reinterpret_cast<const double2*>(tt + buf * KT)[c + 16 * jj];
+            tq[2 * jj] = t2.x;
+            tq[2 * jj + 1] = t2.y;
+        }
 
         // A. partial normalisers over this lane's topics -> LDS transpose -> sum over the 16 topic lanes
 #pragma unroll
@@ -185,8 +195,8 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
 #pragma unroll
         for (int m = 0; m < QV; ++m) {
             const double v = swap16_add(u[m], u[m + QV]);
-            const int slot = m + (g & 1) * QV + (g >> 1) * (KRL / 2);
-            sp[wave * KT + c + 16 * slot] = v;
+            const int slot = m + (g & 1) * QV + (g >> 1) * (KRL / 2);      // register index j of the topic
+            sp[wave * KT + 2 * c + (slot & 1) + 32 * (slot >> 1)] = v;
         }
         __syncthreads();
 
@@ -228,16 +238,24 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     // ---- document terms (:195-204) with the last phi = B t r (see estep_slab.h) ----
     double tq[KRL];
 #pragma unroll
-    for (int j = 0; j < KRL; ++j) tq[j] = tt[last * KT + c + 16 * j];
+    for (int jj = 0; jj < KRL / 2; ++jj) {
+        const double2 t2 = reinterpret_cast<const double2*>(tt + last * KT)[c + 16 * jj];
+        tq[2 * jj] = t2.x;
+        tq[2 * jj + 1] = t2.y;
+    }
     double term1 = 0.0;
+    const bool do_term1 = p.heldout || p.want_doc_ll;     // else: taken per corpus from the statistics
 #pragma unroll
     for (int i = 0; i < RWL; ++i) {
         const int n = wb + i;
-        if (n < N) {
-            const double* row = p.expElog_elog + (size_t)p.term_id[lo + n] * ldk + c;
-            double gsum2 = row[0] * tq[0];
+        if (n < N && do_term1) {
+            const double2* row = reinterpret_cast<const double2*>(p.expElog_elog + (size_t)p.term_id[lo + n] * ldk) + c;
+            double gsum2 = 0.0;
 #pragma unroll
-            for (int j = 1; j < KRL; ++j) gsum2 = fma(row[16 * j], tq[j], gsum2);
+            for (int jj = 0; jj < KRL / 2; ++jj) {
+                const double2 g2 = row[16 * jj];
+                gsum2 = fma(g2.y, tq[2 * jj + 1], fma(g2.x, tq[2 * jj], gsum2));
+            }
             term1 = fma(myrr[g * RWL + i], gsum2, term1);
         }
     }

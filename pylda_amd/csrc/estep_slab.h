@@ -233,9 +233,10 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
 #pragma unroll
     for (int j = 0; j < RK; ++j) ts[j] = readlane_f64(tv, j * LP);
     double term1 = 0.0;
+    const bool do_term1 = p.heldout || p.want_doc_ll;     // else: taken per corpus from the statistics
 #pragma unroll
     for (int i = 0; i < RN; ++i) {
-        if (lane + kWave * i < N) {
+        if (lane + kWave * i < N && do_term1) {
             const double2* src = reinterpret_cast<const double2*>(p.expElog_elog + (size_t)wid[i] * ldk + k0);
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll

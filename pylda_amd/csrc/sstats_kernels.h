@@ -60,16 +60,26 @@ __global__ __launch_bounds__(256) void sstats_gather_kernel(
 }
 
 // sstats[w][k] = B[w][k] * sum over the word's segments (in order).
+// Also the corpus-level entropy term the document kernels skip on the training
+// fast path:  sum_d sum_n c_n sum_k phi_nk log B[w_n][k] = sum_{w,k} sstats[w][k] * (E_log_eta - shift)[w][k]
+// = sum_{w,k} (B log B)[w][k] * acc[w][k]; one partial per workgroup, summed in order afterwards.
 __global__ __launch_bounds__(256) void sstats_finalize_kernel(
     const int64_t* __restrict__ word_seg_ptr, const double* __restrict__ partial,
-    const double* __restrict__ expElog, int V, int ldk, double* __restrict__ sstats)
+    const double* __restrict__ expElog, const double* __restrict__ expElog_elog, int V, int ldk,
+    double* __restrict__ sstats, double* __restrict__ entropy_partial)
 {
+    __shared__ double scratch[4];
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)V * ldk) return;
-    const int w = (int)(idx / ldk), k = (int)(idx - (int64_t)w * ldk);
-    double s = 0.0;
-    for (int64_t sg = word_seg_ptr[w]; sg < word_seg_ptr[w + 1]; ++sg) s += partial[(size_t)sg * ldk + k];
-    sstats[idx] = expElog[idx] * s;
+    double ent = 0.0;
+    if (idx < (int64_t)V * ldk) {
+        const int w = (int)(idx / ldk), k = (int)(idx - (int64_t)w * ldk);
+        double s = 0.0;
+        for (int64_t sg = word_seg_ptr[w]; sg < word_seg_ptr[w + 1]; ++sg) s += partial[(size_t)sg * ldk + k];
+        sstats[idx] = expElog[idx] * s;
+        ent = expElog_elog[idx] * s;
+    }
+    ent = block_sum<256>(ent, scratch);
+    if (threadIdx.x == 0) entropy_partial[blockIdx.x] = ent;
 }
 
 }  // namespace pylda

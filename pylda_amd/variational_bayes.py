@@ -88,6 +88,8 @@ class VariationalBayes(Inferencer):
         if self._ctx is None:
             self._ctx = _capi.Context(self._number_of_topics, self._number_of_types, self._device)
             self._eta_host_newer = True
+            # the reference's API exposes corpus-level likelihoods only (:214,:216)
+            self._ctx.set_option("doc_values", 0)
             if self._process_group is not None:
                 # run on torch's current stream so the RCCL all-reduce issued through
                 # torch.distributed is stream-ordered with the kernels, no host sync

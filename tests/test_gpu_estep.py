@@ -223,6 +223,44 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
 
 
+@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6])
+def test_training_fast_path_corpus_likelihood(capi, ap_train, variant):
+    """Option doc_values=0 (what learning() uses): the corpus-level document_log_likelihood must equal
+    the sum of the complete per-document values, and the reference's own corpus value."""
+    g = ap_train
+    rng = np.random.default_rng(variant)
+    for K, eta, alpha, ptr, tid, tct, ref_ll in (
+            (10, g["eta"], g["alpha"], g["doc_ptr"], g["term_id"], g["term_ct"], float(g["corpus_ll"])),
+            (100, None, None, g["doc_ptr"][:301], g["term_id"], g["term_ct"], None)):
+        if eta is None:
+            eta = rng.gamma(100.0, 0.01, (K, 6806))
+            alpha = rng.uniform(0.05, 1.0, K)
+            tid, tct = tid[:ptr[-1]], tct[:ptr[-1]]
+        ctx = capi.Context(K, 6806)
+        ctx.set_option("force_variant", variant)
+        corpus = ctx.corpus(ptr, tid, tct)
+        ctx.set_alpha(alpha)
+        ctx.set_eta(eta)
+        ctx.set_option("doc_values", 1)
+        ctx.estep(corpus)
+        full_ll = ctx.estep_results(corpus)[0]
+        doc_ll = ctx.get_doc_values(corpus)[0]
+        sst_full = ctx.get_sstats()
+        ctx.set_option("doc_values", 0)
+        ctx.estep(corpus)
+        fast_ll = ctx.estep_results(corpus)[0]
+        assert abs(fast_ll - full_ll) < 1e-11 * abs(full_ll)
+        assert abs(doc_ll.sum() - full_ll) < 1e-11 * abs(full_ll)
+        assert np.array_equal(ctx.get_sstats(), sst_full)
+        if ref_ll is not None:
+            assert abs(fast_ll - ref_ll) < 1e-9 * abs(ref_ll)
+        with pytest.raises(capi.PyldaError) as e:
+            ctx.get_doc_values(corpus)
+        assert e.value.status == -4
+        corpus.close()
+        ctx.close()
+
+
 def test_edge_cases_empty_ragged_and_limits(capi):
     from oracle import c_oracle
     rng = np.random.default_rng(0)
