@@ -85,6 +85,7 @@ struct pylda_ctx {
     int force_logspace = 0;
     int force_variant = -1;
     int column_waves = 8;
+    int quilt12 = 0;
     int doc_values = 1;             // 1: per-document log-likelihoods complete (see EstepParams::want_doc_ll)
     int plan_epoch = 0;
 
@@ -201,20 +202,25 @@ int column_rnw_for(const pylda_ctx* ctx, int n)
     return 0;
 }
 
-// Quilt (2-D lanes, register-resident) kernel: words per lane, or 0.
-int quilt_rwl_for(const pylda_ctx* ctx, int n)
+// Quilt (2-D lanes, register-resident) kernel geometry: wavefronts per document and
+// words per lane (W * 4 * RWL >= n), or W = 0.  12 wavefronts x 4 words per lane keeps a
+// 129..192-term document at 149 VGPRs = 3 wavefronts per SIMD instead of 2.
+struct QuiltGeom { int W, RWL; };
+QuiltGeom quilt_geom_for(const pylda_ctx* ctx, int n)
 {
-    if (ctx->ldk != 64 && ctx->ldk != 128) return 0;
-    if (n <= 64) return 2;
-    if (n <= 128) return 4;
-    if (n <= 256) return 8;
-    return 0;
+    if (ctx->ldk != 64 && ctx->ldk != 128) return {0, 0};
+    if (n <= 64) return {8, 2};
+    if (n <= 128) return {8, 4};
+    if (n <= 192 && ctx->quilt12) return {12, 4};
+    if (n <= 256) return {8, 8};
+    return {0, 0};
 }
+int quilt_rwl_for(const pylda_ctx* ctx, int n) { const QuiltGeom q = quilt_geom_for(ctx, n); return q.W * 100 + q.RWL; }
 
 // Decide the kernel variant for a document with n distinct terms.
 int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
 {
-    if ((ctx->force_variant < 0 || ctx->force_variant == kQuilt) && quilt_rwl_for(ctx, n) > 0) {
+    if ((ctx->force_variant < 0 || ctx->force_variant == kQuilt) && quilt_geom_for(ctx, n).W > 0) {
         *lds_bytes = 0;
         return kQuilt;
     }
@@ -375,9 +381,10 @@ int launch_quilt(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 int launch_quilt_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
     const int KRL = ctx->ldk / 16;
-#define QUILT_CASE(krl_, rwl_) \
-    if (KRL == krl_ && L.rn == rwl_) return launch_quilt<8, krl_, rwl_>(ctx, p, L);
-    QUILT_CASE(4, 2) QUILT_CASE(4, 4) QUILT_CASE(4, 8) QUILT_CASE(8, 2) QUILT_CASE(8, 4) QUILT_CASE(8, 8)
+#define QUILT_CASE(w_, krl_, rwl_) \
+    if (KRL == krl_ && L.rn == w_ * 100 + rwl_) return launch_quilt<w_, krl_, rwl_>(ctx, p, L);
+    QUILT_CASE(8, 4, 2) QUILT_CASE(8, 4, 4) QUILT_CASE(8, 4, 8) QUILT_CASE(8, 8, 2) QUILT_CASE(8, 8, 4) QUILT_CASE(8, 8, 8)
+    QUILT_CASE(12, 4, 4) QUILT_CASE(12, 8, 4)
 #undef QUILT_CASE
     return fail(ctx, PYLDA_ERR_STATE, "no quilt kernel for KRL=%d RWL=%d", KRL, L.rn);
 }
@@ -634,6 +641,9 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         if (value < -1 || value > kQuilt)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
+        ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "quilt12")) {
+        ctx->quilt12 = value != 0;
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "doc_values")) {
         ctx->doc_values = value != 0;
