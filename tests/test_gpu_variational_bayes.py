@@ -138,3 +138,39 @@ def test_exports(ap_model, tmp_path):
     assert len(rows) == 2000 and len(rows[0].split("\t")) == 10
     probs = [float(x.split(":")[1]) for x in rows[0].split("\t")]
     assert probs == sorted(probs, reverse=True) and abs(sum(probs) - 1.0) < 1e-4
+
+
+def test_launch_train_and_launch_test_drivers(ap_train, ap_test, tmp_path, capsys):
+    """The launch_train / launch_test command lines end to end on a small on-disk corpus:
+    output layout (launch_train.py:127-162,199-204) and the held-out flow (launch_test.py:90-97)."""
+    from pylda_amd import launch_test, launch_train
+    g = ap_train
+    words = [str(w) for w in g["words"]]
+    corpus_dir = tmp_path / "mini-press"
+    corpus_dir.mkdir()
+    docs = documents_from_csr(words, g["doc_ptr"][:121], g["term_id"], g["term_ct"])
+    (corpus_dir / "train.dat").write_text("\n".join(d.upper() for d in docs[:100]) + "\n")     # lower-cased on load
+    (corpus_dir / "test.dat").write_text("\n".join(docs[100:120]) + "\n")
+    (corpus_dir / "voc.dat").write_text("".join("%s\t1\t1\n" % w for w in words))
+    out_dir = tmp_path / "out"
+    np.random.seed(3)
+    rc = launch_train.main(["--input_directory=%s/" % corpus_dir, "--output_directory=%s" % out_dir,
+                            "--number_of_topics=5", "--training_iterations=4", "--snapshot_interval=2"])
+    assert rc == 0
+    runs = list((out_dir / "mini-press").iterdir())
+    assert len(runs) == 1 and "-lda-I4-S2-K5-aa0.200000-ab" in runs[0].name and runs[0].name.endswith("-im2")
+    names = sorted(p.name for p in runs[0].iterdir())
+    assert names == ["exp_beta-2", "exp_beta-4", "exp_gamma-2", "exp_gamma-4", "model-4", "option.txt"]
+    opts = dict(l.split("=", 1) for l in (runs[0] / "option.txt").read_text().splitlines())
+    assert opts["number_of_topics"] == "5" and opts["inference_mode"] == "2" and opts["corpus_name"] == "mini-press"
+    assert len((runs[0] / "exp_gamma-4").read_text().splitlines()) == 100
+    assert launch_train.main(["--input_directory=%s" % corpus_dir, "--output_directory=%s" % out_dir,
+                              "--number_of_topics=5", "--training_iterations=1", "--inference_mode=0"]) == 2
+    capsys.readouterr()
+    rc = launch_test.main(["--input_directory=%s" % corpus_dir, "--model_directory=%s" % runs[0],
+                           "--snapshot_index=4"])
+    assert rc == 0
+    printed = capsys.readouterr().out
+    assert "held-out likelihood of snapshot" in printed
+    gamma = np.loadtxt(runs[0] / "test-4")
+    assert gamma.shape == (20, 5) and np.all(gamma > 0)
