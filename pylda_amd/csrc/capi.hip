@@ -23,6 +23,7 @@
 #include "estep_slab.h"
 #include "estep_column.h"
 #include "estep_quilt.h"
+#include "estep_qstream.h"
 #include "mstep_kernels.h"
 #include "prepare_kernels.h"
 #include "sstats_kernels.h"
@@ -40,7 +41,8 @@ enum Variant : int {
     kGenericGlobal = 3, // tile larger than LDS: rows re-read from the table
     kSlab = 4,          // tile in registers, word-major lanes (estep_slab.h)
     kColumn = 5,        // tile in registers, topic-major lanes (estep_column.h)
-    kQuilt = 6          // tile in registers, 4 x 16 word-group x topic lanes (estep_quilt.h)
+    kQuilt = 6,         // tile in registers, 4 x 16 word-group x topic lanes (estep_quilt.h)
+    kQstream = 7        // tile streamed from L2 twice per iteration, quilt lanes (estep_qstream.h)
 };
 
 struct Launch {
@@ -217,6 +219,9 @@ QuiltGeom quilt_geom_for(const pylda_ctx* ctx, int n)
 }
 int quilt_rwl_for(const pylda_ctx* ctx, int n) { const QuiltGeom q = quilt_geom_for(ctx, n); return q.W * 100 + q.RWL; }
 
+// Streaming quilt kernel: any ldk that is a multiple of 64 up to 512, documents up to 1000 terms.
+bool qstream_ok(const pylda_ctx* ctx, int n) { return ctx->ldk % 64 == 0 && ctx->ldk <= 512 && n <= 1000; }
+
 // Decide the kernel variant for a document with n distinct terms.
 int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
 {
@@ -231,6 +236,10 @@ int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
     if ((ctx->force_variant < 0 || ctx->force_variant == kSlab) && slab_geom_for(ctx, n).W > 0) {
         *lds_bytes = 0;
         return kSlab;
+    }
+    if ((ctx->force_variant < 0 || ctx->force_variant == kQstream) && qstream_ok(ctx, n)) {
+        *lds_bytes = 0;
+        return kQstream;
     }
     const int K = ctx->K, stride = tile_stride_for(K);
     const size_t l64 = generic_lds_layout(K, n, stride, 64, false).total;
@@ -387,6 +396,34 @@ int launch_quilt_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     QUILT_CASE(12, 4, 4) QUILT_CASE(12, 8, 4)
 #undef QUILT_CASE
     return fail(ctx, PYLDA_ERR_STATE, "no quilt kernel for KRL=%d RWL=%d", KRL, L.rn);
+}
+
+template <int KRL>
+int launch_qstream(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    auto kern = estep_qstream_kernel<8, KRL>;
+    const size_t lds = QstreamLds<8, KRL>::total;
+    if (lds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * 8), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+int launch_qstream_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    switch (ctx->ldk / 16) {
+    case 4: return launch_qstream<4>(ctx, p, L);
+    case 8: return launch_qstream<8>(ctx, p, L);
+    case 12: return launch_qstream<12>(ctx, p, L);
+    case 16: return launch_qstream<16>(ctx, p, L);
+    case 20: return launch_qstream<20>(ctx, p, L);
+    case 24: return launch_qstream<24>(ctx, p, L);
+    case 28: return launch_qstream<28>(ctx, p, L);
+    case 32: return launch_qstream<32>(ctx, p, L);
+    }
+    return fail(ctx, PYLDA_ERR_STATE, "no streaming kernel for table stride %d", ctx->ldk);
 }
 
 int enqueue_prepare(pylda_ctx* ctx, bool heldout)
@@ -638,7 +675,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kQuilt)
+        if (value < -1 || value > kQstream)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
@@ -885,6 +922,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kSlab: rc = launch_slab_any(ctx, p, L); break;
             case kColumn: rc = launch_column_any(ctx, p, L); break;
             case kQuilt: rc = launch_quilt_any(ctx, p, L); break;
+            case kQstream: rc = launch_qstream_any(ctx, p, L); break;
             default: rc = launch_generic<256, true>(ctx, p, L); break;
             }
             if (rc != PYLDA_OK) return rc;

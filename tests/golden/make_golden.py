@@ -19,6 +19,8 @@ Fixtures
   ap_trace_k10.npz   per-iteration joint log-likelihood / alpha trace
   special_fn.npz     scipy psi / gammaln / polygamma samples used to pin the
                      C oracle's and the HIP kernel's special functions
+  nips_k500.npz      parsed/nips.88-05, K=500, 48 training + 16 held-out documents
+                     (up to ~480 distinct terms): first E-step from the seeded eta
 """
 import argparse
 import io
@@ -194,6 +196,42 @@ def make_ap(vb, trace_iters):
     print("ap_trace_k10: %d iterations, final held-out words_ll=%r" % (len(trace_ll), wll_end))
 
 
+def make_nips(vb):
+    """BASELINE.json cfg 5 in miniature: parsed/nips.88-05, K=500 (documents with up to ~480
+    distinct terms: the tile does not fit on chip, so this pins the large-K / long-document
+    kernels against the reference itself).  eta is NOT stored (500 x 3209 doubles): it is the
+    reference's own seeded draw, numpy.random.seed(5); gamma(100, 0.01, (K, V)) - numpy's legacy
+    stream is stable across versions - and the test regenerates it."""
+    tf = tarfile.open(os.path.join(REFERENCE_ROOT, "parsed", "nips.88-05.tar.gz"))
+    docs = tf.extractfile("nips.88-05/doc.dat").read().decode("utf-8").splitlines()
+    vocab = [l.strip().lower().split()[0] for l in
+             tf.extractfile("nips.88-05/voc.dat").read().decode("utf-8").splitlines() if l.strip()]
+    vocab = list(dict.fromkeys(vocab))
+    docs = [l.strip().lower() for l in docs]
+    train, test = docs[:48], docs[-16:]
+    K = 500
+    np.random.seed(5)
+    m = vb.VariationalBayes()
+    quiet(m._initialize, train, vocab, K, 1.0 / K, 1.0 / len(vocab))
+    words = np.array([m._index_to_type[i] for i in range(len(vocab))])
+    ptr, tid, tct = csr_of(m._parsed_corpus)
+    gamma, doc_ll, iters = per_document(m, m._parsed_corpus, heldout=False)
+    np.random.seed(50)
+    ll, sstats = quiet(m.e_step)
+    parsed_test = quiet(m.parse_data, test)
+    tptr, ttid, ttct = csr_of(parsed_test)
+    hgamma, hwll, hiters = per_document(m, parsed_test, heldout=True)
+    # sstats are K x V = 12.8 MB: keep column sums, row sums and a strided sample instead
+    np.savez_compressed(
+        os.path.join(HERE, "nips_k500.npz"), words=words, seed=5, K=K, doc_ptr=ptr,
+        term_id=tid.astype(np.int16), term_ct=tct.astype(np.int16), gamma=gamma, doc_ll=doc_ll, iters=iters,
+        corpus_ll=ll, sstats_rowsum=sstats.sum(axis=1), sstats_colsum=sstats.sum(axis=0),
+        sstats_sample=sstats[::7, ::11].copy(), test_doc_ptr=tptr, test_term_id=ttid.astype(np.int16),
+        test_term_ct=ttct.astype(np.int16), heldout_gamma=hgamma, heldout_words_ll=hwll, heldout_iters=hiters)
+    print("nips_k500: %d train docs, max terms %d, corpus_ll=%r, mean iters %.1f"
+          % (len(ptr) - 1, np.diff(ptr).max(), ll, iters.mean()))
+
+
 def make_special():
     rng = np.random.default_rng(3)
     x = np.concatenate([
@@ -209,7 +247,7 @@ def make_special():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--trace", type=int, default=3, help="AP K=10 trace length (iterations)")
-    ap.add_argument("--only", default="", help="comma list of: tiny,ap,special")
+    ap.add_argument("--only", default="", help="comma list of: tiny,ap,special,nips")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
     _, vb = load_reference()
@@ -219,3 +257,5 @@ if __name__ == "__main__":
         make_tiny(vb)
     if not only or "ap" in only:
         make_ap(vb, args.trace)
+    if not only or "nips" in only:
+        make_nips(vb)

@@ -108,7 +108,7 @@ def test_ap_heldout_k10_matches_reference_goldens(capi, ap_test):
     assert abs(out["words_log_likelihood"] - float(g["corpus_words_ll"])) < 1e-9 * abs(float(g["corpus_words_ll"]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_every_kernel_variant_agrees(capi, ap_train, variant):
     g = ap_train
     docs = list(range(0, 2000, 10))
@@ -208,7 +208,7 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
     ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
     gen = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 1)])
     held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
-    for variant in (4, 5, 6):                    # slab (word-major), column (topic-major), quilt (2-D lanes)
+    for variant in (4, 5, 6, 7):                 # slab, column, quilt (register tiles), streaming quilt
         out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
         check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
         assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
@@ -223,7 +223,7 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6, 7])
 def test_training_fast_path_corpus_likelihood(capi, ap_train, variant):
     """Option doc_values=0 (what learning() uses): the corpus-level document_log_likelihood must equal
     the sum of the complete per-document values, and the reference's own corpus value."""
@@ -259,6 +259,28 @@ def test_training_fast_path_corpus_likelihood(capi, ap_train, variant):
         assert e.value.status == -4
         corpus.close()
         ctx.close()
+
+
+def test_nips_k500_matches_reference_goldens(capi):
+    """BASELINE.json cfg 5 in miniature (parsed/nips.88-05, K=500, documents up to 482 distinct terms,
+    goldens from the reference itself): exercises the streaming large-K kernel."""
+    g = load_golden("nips_k500.npz")
+    K, V = int(g["K"]), len(g["words"])
+    np.random.seed(int(g["seed"]))
+    eta = np.random.gamma(100., 1. / 100., (K, V))                  # the reference's draw, variational_bayes.py:95
+    alpha = np.full(K, 1.0 / K)
+    ptr, tid, tct = g["doc_ptr"], g["term_id"].astype(np.int32), g["term_ct"].astype(np.int32)
+    for options in ([], [("force_variant", 3)]):                      # automatic (streaming) and generic
+        out = run(capi, alpha, eta, ptr, tid, tct, options=options)
+        assert out["logspace_docs"] == 0
+        check_against(out, g["gamma"], g["doc_ll"], g["iters"])
+        assert abs(out["document_log_likelihood"] - float(g["corpus_ll"])) < 1e-9 * abs(float(g["corpus_ll"]))
+        assert np.max(np.abs(out["sstats"].sum(axis=1) - g["sstats_rowsum"])) < 1e-8
+        assert np.max(np.abs(out["sstats"].sum(axis=0) - g["sstats_colsum"])) < 1e-8
+        assert np.max(np.abs(out["sstats"][::7, ::11] - g["sstats_sample"])) < 1e-9
+    held = run(capi, alpha, eta, g["test_doc_ptr"], g["test_term_id"].astype(np.int32),
+               g["test_term_ct"].astype(np.int32), heldout=True)
+    check_against(held, g["heldout_gamma"], g["heldout_words_ll"], g["heldout_iters"], ll_key="doc_words_ll")
 
 
 def test_edge_cases_empty_ragged_and_limits(capi):
