@@ -63,6 +63,13 @@ struct pylda_ctx {
     int K = 0, V = 0;
     int ldk = 0;                    // row stride of the word-major tables
     hipStream_t own_stream = nullptr;
+    // A corpus whose documents fall into several launch classes (different words-per-lane
+    // instantiations) has independent launches: they are fanned out over these streams so a
+    // small corpus pays one kernel latency (50 serial inner iterations), not one per class.
+    static constexpr int kAux = 4;
+    hipStream_t aux_stream[kAux] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_event = nullptr;
+    hipEvent_t join_event[kAux] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream = nullptr;
     size_t lds_limit = 64 * 1024;
     int num_cu = 256;
@@ -616,6 +623,11 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     CREATE_TRY(hip_ok(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking),
                       "hipStreamCreate"));
     ctx->stream = ctx->own_stream;
+    for (int i = 0; i < pylda_ctx::kAux; ++i) {
+        CREATE_TRY(hip_ok(hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking), "hipStreamCreate"));
+        CREATE_TRY(hip_ok(hipEventCreateWithFlags(&ctx->join_event[i], hipEventDisableTiming), "hipEventCreate"));
+    }
+    CREATE_TRY(hip_ok(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming), "hipEventCreate"));
     const size_t kv = (size_t)K * V, wk = (size_t)V * ctx->ldk;
     CREATE_TRY(dev_alloc(ctx, &ctx->d_eta, kv));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_elog, wk));
@@ -649,6 +661,11 @@ void pylda_destroy(pylda_ctx* ctx)
     dev_free(ctx->d_kv_scratch); dev_free(ctx->d_shift); dev_free(ctx->d_beta);
     dev_free(ctx->d_psi_rowsum); dev_free(ctx->d_topic_lse); dev_free(ctx->d_alpha);
     dev_free(ctx->d_small); dev_free(ctx->d_partial); dev_free(ctx->d_flag_count);
+    for (int i = 0; i < pylda_ctx::kAux; ++i) {
+        if (ctx->aux_stream[i]) { (void)hipStreamSynchronize(ctx->aux_stream[i]); (void)hipStreamDestroy(ctx->aux_stream[i]); }
+        if (ctx->join_event[i]) (void)hipEventDestroy(ctx->join_event[i]);
+    }
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -911,7 +928,16 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
                                     hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     } else {
+        hipStream_t main_stream = ctx->stream;
+        const bool fan_out = c->plan.size() > 1;
+        const int used = fan_out ? (int)std::min<size_t>(pylda_ctx::kAux, c->plan.size()) : 0;
+        if (fan_out) {
+            HIP_TRY(ctx, hipEventRecord(ctx->fork_event, main_stream));
+            for (int i = 0; i < used; ++i) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream[i], ctx->fork_event, 0));
+        }
+        size_t launch_index = 0;
         for (const Launch& L : c->plan) {
+            if (fan_out) ctx->stream = ctx->aux_stream[launch_index++ % pylda_ctx::kAux];
             p.order = c->d_order + L.first;
             p.n_cap = L.n_cap;
             p.tile_stride = L.tile_stride;
@@ -925,7 +951,15 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kQstream: rc = launch_qstream_any(ctx, p, L); break;
             default: rc = launch_generic<256, true>(ctx, p, L); break;
             }
-            if (rc != PYLDA_OK) return rc;
+            if (rc != PYLDA_OK) {
+                ctx->stream = main_stream;
+                return rc;
+            }
+        }
+        ctx->stream = main_stream;
+        for (int i = 0; i < used; ++i) {
+            HIP_TRY(ctx, hipEventRecord(ctx->join_event[i], ctx->aux_stream[i]));
+            HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->join_event[i], 0));
         }
     }
     if (ctx->profiling) {
