@@ -163,6 +163,20 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value);
 int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digamma_out,
                        double* lgamma_out);
 
+/* Native corpus ingest: parse_data (variational_bayes.py:98-130) without the Python
+ * interpreter.  `text` holds the documents, one per line ('\n'), tokens separated by
+ * blanks; `vocab` holds the word types, one per line, in id order (id = line number).
+ * Rules kept from the reference: tokens not in the vocabulary are skipped (:108-109),
+ * documents left without tokens are dropped (:116-118); the caller lower-cases/strips
+ * lines beforehand if it wants launch_train.py:106 semantics (ASCII lower-casing can be
+ * requested with lowercase=1).  Within a document, term ids appear in first-occurrence
+ * order (what the reference's dict gives on CPython >= 3.7).
+ * Two-call protocol: call with term_id == NULL to get the sizes (*n_docs, *nnz), then
+ * with buffers of n_docs+1 / nnz / nnz elements.  Pure host code: no GPU needed. */
+int pylda_parse_corpus(const char* text, int64_t text_bytes, const char* vocab, int64_t vocab_bytes,
+                       int lowercase, int64_t* n_docs, int64_t* nnz, int64_t* doc_ptr,
+                       int32_t* term_id, int32_t* term_ct, int64_t* dropped_docs);
+
 /* Test hook: out[i] = exp(digamma(x[i]) - c), the fused form the inner loop uses. */
 int pylda_test_expdigamma(pylda_ctx* ctx, int64_t n, const double* x, double c, double* out);
 

@@ -51,6 +51,9 @@ SIGNATURES = {
     "pylda_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pylda_kernel_time": (ctypes.c_int, [_vp, _c_double_p, _c_int64_p]),
     "pylda_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
+    "pylda_parse_corpus": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64,
+                                          ctypes.c_int, _c_int64_p, _c_int64_p, _c_int64_p, _c_int32_p,
+                                          _c_int32_p, _c_int64_p]),
     "pylda_test_expdigamma": (ctypes.c_int, [_vp, ctypes.c_int64, _c_double_p, ctypes.c_double, _c_double_p]),
     "pylda_test_special": (ctypes.c_int, [_vp, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p]),
 }
@@ -97,6 +100,29 @@ class PyldaError(RuntimeError):
     def __init__(self, status, message):
         RuntimeError.__init__(self, "pylda_hip error %d: %s" % (status, message))
         self.status = status
+
+
+def parse_corpus(lines, vocabulary, lowercase=False):
+    """Native parse_data (variational_bayes.py:98-130): documents (iterable of str) and the
+    vocabulary in id order -> CSR (doc_ptr int64, term_id int32, term_ct int32), #dropped."""
+    lib = load()
+    text = "\n".join(lines).encode("utf-8")
+    vocab = "\n".join(vocabulary).encode("utf-8")
+    n_docs, nnz, dropped = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    rc = lib.pylda_parse_corpus(text, len(text), vocab, len(vocab), 1 if lowercase else 0,
+                                ctypes.byref(n_docs), ctypes.byref(nnz), None, None, None, None)
+    if rc != 0:
+        raise PyldaError(rc, "pylda_parse_corpus (sizing pass)")
+    doc_ptr = np.zeros(n_docs.value + 1, dtype=np.int64)
+    term_id = np.zeros(max(nnz.value, 1), dtype=np.int32)
+    term_ct = np.zeros(max(nnz.value, 1), dtype=np.int32)
+    rc = lib.pylda_parse_corpus(text, len(text), vocab, len(vocab), 1 if lowercase else 0,
+                                ctypes.byref(n_docs), ctypes.byref(nnz),
+                                doc_ptr.ctypes.data_as(_c_int64_p), term_id.ctypes.data_as(_c_int32_p),
+                                term_ct.ctypes.data_as(_c_int32_p), ctypes.byref(dropped))
+    if rc != 0:
+        raise PyldaError(rc, "pylda_parse_corpus")
+    return doc_ptr, term_id[:nnz.value], term_ct[:nnz.value], dropped.value
 
 
 def device_count():

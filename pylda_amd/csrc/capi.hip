@@ -15,6 +15,8 @@
 #include <new>
 #include <numeric>
 #include <string>
+#include <string_view>
+#include <unordered_map>
 #include <vector>
 
 #include "estep_common.h"
@@ -1219,6 +1221,91 @@ int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digam
     }
     dev_free(dx); dev_free(dd); dev_free(dl);
     return rc;
+}
+
+int pylda_parse_corpus(const char* text, int64_t text_bytes, const char* vocab, int64_t vocab_bytes,
+                       int lowercase, int64_t* n_docs, int64_t* nnz, int64_t* doc_ptr,
+                       int32_t* term_id, int32_t* term_ct, int64_t* dropped_docs)
+{
+    if (!text || !vocab || text_bytes < 0 || vocab_bytes < 0 || !n_docs || !nnz) return PYLDA_ERR_INVALID;
+    const bool fill = term_id != nullptr;
+    if (fill && (!doc_ptr || !term_ct)) return PYLDA_ERR_INVALID;
+    try {
+        auto blank = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f'; };
+        // vocabulary: one type per line, id = line index (first occurrence wins, as parse_vocabulary)
+        std::unordered_map<std::string_view, int32_t> lookup;
+        lookup.reserve((size_t)(vocab_bytes / 6 + 16));
+        {
+            int32_t next = 0;
+            const char *p = vocab, *end = vocab + vocab_bytes;
+            while (p < end) {
+                const char* eol = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+                if (!eol) eol = end;
+                const char *a = p, *b = eol;
+                while (a < b && blank(*a)) ++a;
+                while (b > a && blank(b[-1])) --b;
+                if (b > a && lookup.emplace(std::string_view(a, (size_t)(b - a)), next).second) ++next;
+                p = eol + 1;
+            }
+        }
+        std::string lowered;
+        std::vector<int32_t> slot;          // term id -> position in this document's list, -1 if absent
+        slot.assign(lookup.size(), -1);
+        std::vector<int32_t> ids, cts;
+        int64_t docs = 0, entries = 0, dropped = 0;
+        if (fill) doc_ptr[0] = 0;
+        const char *p = text, *end = text + text_bytes;
+        while (p < end) {
+            const char* eol = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+            if (!eol) eol = end;
+            ids.clear();
+            cts.clear();
+            const char* q = p;
+            while (q < eol) {
+                while (q < eol && blank(*q)) ++q;
+                const char* tok = q;
+                while (q < eol && !blank(*q)) ++q;
+                if (q == tok) break;
+                std::string_view key(tok, (size_t)(q - tok));
+                if (lowercase) {
+                    lowered.assign(tok, q);
+                    for (char& ch : lowered)
+                        if (ch >= 'A' && ch <= 'Z') ch = (char)(ch - 'A' + 'a');
+                    key = lowered;
+                }
+                const auto hit = lookup.find(key);
+                if (hit == lookup.end()) continue;                         // :108-109
+                int32_t& at = slot[(size_t)hit->second];
+                if (at < 0) {
+                    at = (int32_t)ids.size();
+                    ids.push_back(hit->second);
+                    cts.push_back(1);
+                } else {
+                    cts[(size_t)at] += 1;
+                }
+            }
+            for (int32_t id : ids) slot[(size_t)id] = -1;
+            const bool had_text = eol > p || eol < end;                    // a line exists (even if empty)
+            if (!ids.empty()) {
+                if (fill) {
+                    memcpy(term_id + entries, ids.data(), ids.size() * sizeof(int32_t));
+                    memcpy(term_ct + entries, cts.data(), cts.size() * sizeof(int32_t));
+                    doc_ptr[docs + 1] = entries + (int64_t)ids.size();
+                }
+                entries += (int64_t)ids.size();
+                ++docs;
+            } else if (had_text) {
+                ++dropped;                                                 // :116-118
+            }
+            p = eol + 1;
+        }
+        *n_docs = docs;
+        *nnz = entries;
+        if (dropped_docs) *dropped_docs = dropped;
+    } catch (const std::bad_alloc&) {
+        return PYLDA_ERR_OOM;
+    }
+    return PYLDA_OK;
 }
 
 int pylda_test_expdigamma(pylda_ctx* ctx, int64_t n, const double* x, double c, double* out)

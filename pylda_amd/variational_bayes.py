@@ -22,7 +22,7 @@ import numpy
 import scipy.special
 
 from pylda_amd import _capi
-from pylda_amd.corpus import lists_to_csr
+from pylda_amd.corpus import csr_to_lists, lists_to_csr
 from pylda_amd.inferencer import Inferencer, compute_dirichlet_expectation
 
 
@@ -99,9 +99,24 @@ class VariationalBayes(Inferencer):
 
     def _training_corpus(self):
         if self._train_corpus is None:
-            ptr, ids, cts = lists_to_csr(*self._parsed_corpus)
-            self._train_corpus = self._context().corpus(ptr, ids, cts)
+            csr = self.__dict__.get("_train_csr")
+            if csr is None:
+                csr = lists_to_csr(*self._parsed_corpus)
+            self._train_corpus = self._context().corpus(*csr)
         return self._train_corpus
+
+    @property
+    def _parsed_corpus(self):
+        """The reference's container (:120-121), built on demand from the CSR the native parser made."""
+        if self.__dict__.get("_parsed_lists") is None and self.__dict__.get("_train_csr") is not None:
+            self._parsed_lists = csr_to_lists(*self._train_csr)
+        return self.__dict__.get("_parsed_lists")
+
+    @_parsed_corpus.setter
+    def _parsed_corpus(self, value):
+        self._parsed_lists = value
+        self._train_csr = None
+        self._train_corpus = None        # the device copy is rebuilt from the new container
 
     def _push_model(self):
         ctx = self._context()
@@ -115,8 +130,9 @@ class VariationalBayes(Inferencer):
         """variational_bayes.py:82-96 (same RNG draw for eta, so a seeded run
         starts from the reference's own initial state)."""
         Inferencer._initialize(self, vocab, number_of_topics, alpha_alpha, alpha_beta)
-        self._parsed_corpus = self.parse_data(corpus)
-        self._number_of_documents = len(self._parsed_corpus[0])
+        self._parsed_corpus = None
+        self._train_csr = self.parse_to_csr(corpus)
+        self._number_of_documents = len(self._train_csr[0]) - 1
         self._gamma = (numpy.zeros((self._number_of_documents, self._number_of_topics))
                        + self._alpha_alpha[numpy.newaxis, :]
                        + 1.0 * self._number_of_types / self._number_of_topics)          # :92
@@ -137,6 +153,7 @@ class VariationalBayes(Inferencer):
         self._alpha_alpha = numpy.zeros(self._number_of_topics) + alpha_alpha
         self._alpha_beta = numpy.zeros(self._number_of_types) + alpha_beta
         self._parsed_corpus = None
+        self._train_csr = (numpy.asarray(doc_ptr), numpy.asarray(term_id), numpy.asarray(term_ct))
         self._number_of_documents = len(doc_ptr) - 1
         self._gamma = None
         if eta is None:
@@ -145,31 +162,22 @@ class VariationalBayes(Inferencer):
         self._ctx = None
         self._train_corpus = self._context().corpus(doc_ptr, term_id, term_ct)
 
-    def parse_data(self, corpus):
-        """Text lines -> ([ids (N_d,)], [counts (1, N_d)]) (variational_bayes.py:98-130):
-        tokens outside the vocabulary are skipped (:108-109), documents left
-        empty are dropped with a warning (:116-118)."""
-        word_ids, word_cts = [], []
-        lookup = self._type_to_index
-        doc_count = 0
-        for document_line in corpus:
-            tally = {}
-            for token in document_line.split():
-                type_id = lookup.get(token)
-                if type_id is not None:
-                    tally[type_id] = tally.get(type_id, 0) + 1
-            if not tally:
-                sys.stderr.write("warning: document collapsed during parsing")
-                continue
-            word_ids.append(numpy.fromiter(tally.keys(), dtype=numpy.int64, count=len(tally)))
-            word_cts.append(numpy.fromiter(tally.values(), dtype=numpy.int64,
-                                           count=len(tally))[numpy.newaxis, :])
-            doc_count += 1
-            if self._verbose and doc_count % 10000 == 0:
-                print("successfully parse %d documents..." % doc_count)
+    def parse_to_csr(self, corpus):
+        """Text lines -> CSR (doc_ptr, term_id, term_ct) with the rules of parse_data
+        (variational_bayes.py:98-130): tokens outside the vocabulary are skipped (:108-109),
+        documents left empty are dropped with a warning (:116-118).  Runs in the native
+        library (pylda_parse_corpus): Python dict parsing dominates start-up at 1M documents."""
+        vocabulary = [self._index_to_type[i] for i in range(len(self._index_to_type))]
+        doc_ptr, term_id, term_ct, dropped = _capi.parse_corpus(list(corpus), vocabulary)
+        for _ in range(dropped):
+            sys.stderr.write("warning: document collapsed during parsing")
         if self._verbose:
-            print("successfully parse %d documents..." % (doc_count))
-        return (word_ids, word_cts)
+            print("successfully parse %d documents..." % (len(doc_ptr) - 1))
+        return doc_ptr, term_id, term_ct
+
+    def parse_data(self, corpus):
+        """The reference's signature and container: ([ids (N_d,)], [counts (1, N_d)])."""
+        return csr_to_lists(*self.parse_to_csr(corpus))
 
     # ---------------------------------------------------------------- E-step
     def e_step(self, parsed_corpus=None, local_parameter_iteration=50,
@@ -189,9 +197,12 @@ class VariationalBayes(Inferencer):
             document_log_likelihood, _, _ = ctx.estep_results(corpus)
             self._gamma_host_stale = self._gamma_on_device = True
             return document_log_likelihood, ctx.get_sstats()
-        word_ids, word_cts = parsed_corpus
-        assert len(word_ids) == len(word_cts)                                   # :140
-        corpus = ctx.corpus(*lists_to_csr(word_ids, word_cts))
+        if len(parsed_corpus) == 3:                       # already CSR (inference fast path)
+            corpus = ctx.corpus(*parsed_corpus)
+        else:
+            word_ids, word_cts = parsed_corpus
+            assert len(word_ids) == len(word_cts)                               # :140
+            corpus = ctx.corpus(*lists_to_csr(word_ids, word_cts))
         try:
             ctx.estep(corpus, local_parameter_iteration, local_parameter_converge_threshold, True)
             _, words_log_likelihood, _ = ctx.estep_results(corpus)
@@ -262,7 +273,7 @@ class VariationalBayes(Inferencer):
 
     def inference(self, corpus):
         """variational_bayes.py:263-271."""
-        parsed_corpus = self.parse_data(corpus)
+        parsed_corpus = self.parse_to_csr(corpus)
         words_log_likelihood, corpus_gamma_values = self.e_step(parsed_corpus)
         return words_log_likelihood, corpus_gamma_values
 

@@ -93,3 +93,49 @@ def test_synthetic_generators_small():
     p3, i3, c3 = C.synthetic_lda_corpus_torch(300, 200, 5, 30, seed=3, chunk=100, first_chunk=1, shard_chunks=1)
     assert np.array_equal(i3, i2[p2[100]:p2[200]]) and np.array_equal(c3, c2[p2[100]:p2[200]])
     assert abs(c2.sum() / 300.0 - 30) < 3                               # mean length as requested
+
+
+def reference_rules_parse(lines, type_to_index):
+    """The parse_data rules (variational_bayes.py:104-121) spelled out in plain Python."""
+    ids, cts = [], []
+    for line in lines:
+        tally = {}
+        for token in line.split():
+            if token in type_to_index:
+                tally[type_to_index[token]] = tally.get(type_to_index[token], 0) + 1
+        if tally:
+            ids.append(list(tally.keys()))
+            cts.append(list(tally.values()))
+    return ids, cts
+
+
+def test_native_ingest_matches_parse_data_rules(ap_train):
+    from pylda_amd import _capi
+    rng = np.random.default_rng(4)
+    words = [str(w) for w in ap_train["words"][:500]]
+    lines = []
+    for _ in range(300):
+        n = int(rng.integers(0, 40))
+        toks = [words[i] for i in rng.integers(0, 500, n)] + ["zzzoov"] * int(rng.integers(0, 3))
+        rng.shuffle(toks)
+        lines.append(("  " if rng.random() < 0.2 else "") + " ".join(toks) + ("\t " if rng.random() < 0.2 else ""))
+    lines += ["", "zzzoov qqqoov", words[3], " ".join([words[7]] * 1000)]
+    ptr, tid, tct, dropped = _capi.parse_corpus(lines, words)
+    ref_ids, ref_cts = reference_rules_parse(lines, {w: i for i, w in enumerate(words)})
+    assert len(ptr) - 1 == len(ref_ids) and dropped == len(lines) - len(ref_ids)
+    for d, (ri, rc) in enumerate(zip(ref_ids, ref_cts)):
+        assert tid[ptr[d]:ptr[d + 1]].tolist() == ri            # same ids, same (first-occurrence) order
+        assert tct[ptr[d]:ptr[d + 1]].tolist() == rc
+    assert tct[-1] == 1000 and tid.dtype == np.int32 and ptr.dtype == np.int64
+    # upper-case input is only matched when lower-casing is requested (launch_train.py:106 does it beforehand)
+    up = [l.upper() for l in lines[:50]]
+    p2, t2, c2, _ = _capi.parse_corpus(up, words, lowercase=True)
+    p1, t1, c1, _ = _capi.parse_corpus(lines[:50], words)
+    assert np.array_equal(p1, p2) and np.array_equal(t1, t2) and np.array_equal(c1, c2)
+    p3, t3, _, d3 = _capi.parse_corpus(up, words)
+    assert len(p3) == 1 and t3.size == 0 and d3 == sum(1 for l in up if l.strip() or True)
+    # duplicate vocabulary entries keep their first id; empty corpus
+    p4, t4, c4, _ = _capi.parse_corpus(["b a b"], ["a", "b", "a"])
+    assert t4.tolist() == [1, 0] and c4.tolist() == [2, 1]
+    p5, t5, c5, d5 = _capi.parse_corpus([], ["a"])
+    assert p5.tolist() == [0] and t5.size == 0 and d5 == 0
