@@ -26,6 +26,7 @@
 #include "estep_column.h"
 #include "estep_quilt.h"
 #include "estep_qstream.h"
+#include "estep_qhybrid.h"
 #include "mstep_kernels.h"
 #include "prepare_kernels.h"
 #include "sstats_kernels.h"
@@ -44,7 +45,8 @@ enum Variant : int {
     kSlab = 4,          // tile in registers, word-major lanes (estep_slab.h)
     kColumn = 5,        // tile in registers, topic-major lanes (estep_column.h)
     kQuilt = 6,         // tile in registers, 4 x 16 word-group x topic lanes (estep_quilt.h)
-    kQstream = 7        // tile streamed from L2 twice per iteration, quilt lanes (estep_qstream.h)
+    kQstream = 7,       // tile streamed from L2 twice per iteration, quilt lanes (estep_qstream.h)
+    kQhybrid = 8        // tile split over registers / LDS / streamed remainder (estep_qhybrid.h)
 };
 
 struct Launch {
@@ -228,6 +230,12 @@ QuiltGeom quilt_geom_for(const pylda_ctx* ctx, int n)
 }
 int quilt_rwl_for(const pylda_ctx* ctx, int n) { const QuiltGeom q = quilt_geom_for(ctx, n); return q.W * 100 + q.RWL; }
 
+// Hybrid kernel: 128 < K <= 256 (ldk 192 / 256), or long documents at ldk 64 / 128.
+bool qhybrid_ok(const pylda_ctx* ctx, int n)
+{
+    return ctx->ldk % 64 == 0 && ctx->ldk <= 256 && n <= 128 + 8 * (kQhMaxTail - 4) && ctx->lds_limit >= 160 * 1024;
+}
+
 // Streaming quilt kernel: any ldk that is a multiple of 64 up to 512, documents up to 1000 terms.
 bool qstream_ok(const pylda_ctx* ctx, int n) { return ctx->ldk % 64 == 0 && ctx->ldk <= 512 && n <= 1000; }
 
@@ -245,6 +253,10 @@ int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
     if ((ctx->force_variant < 0 || ctx->force_variant == kSlab) && slab_geom_for(ctx, n).W > 0) {
         *lds_bytes = 0;
         return kSlab;
+    }
+    if ((ctx->force_variant < 0 || ctx->force_variant == kQhybrid) && qhybrid_ok(ctx, n)) {
+        *lds_bytes = 0;
+        return kQhybrid;
     }
     if ((ctx->force_variant < 0 || ctx->force_variant == kQstream) && qstream_ok(ctx, n)) {
         *lds_bytes = 0;
@@ -418,6 +430,32 @@ int launch_qstream(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * 8), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PYLDA_OK;
+}
+
+template <int KRL>
+int launch_qhybrid(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    using Lds = QhybridLds<8, KRL, 4>;
+    auto kern = estep_qhybrid_kernel<8, KRL, 4>;
+    const size_t limit = 160 * 1024;
+    const int rows_per_wave = std::min(kQhMaxTail, Lds::rows_that_fit(limit) / 8);
+    const size_t lds = Lds::fixed_total + (size_t)8 * rows_per_wave * Lds::kRowDoubles * 8;
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * 8), lds, ctx->stream, p, rows_per_wave);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+int launch_qhybrid_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    switch (ctx->ldk / 16) {
+    case 4: return launch_qhybrid<4>(ctx, p, L);
+    case 8: return launch_qhybrid<8>(ctx, p, L);
+    case 12: return launch_qhybrid<12>(ctx, p, L);
+    case 16: return launch_qhybrid<16>(ctx, p, L);
+    }
+    return fail(ctx, PYLDA_ERR_STATE, "no hybrid kernel for table stride %d", ctx->ldk);
 }
 
 int launch_qstream_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
@@ -694,7 +732,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kQstream)
+        if (value < -1 || value > kQhybrid)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
@@ -951,6 +989,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kColumn: rc = launch_column_any(ctx, p, L); break;
             case kQuilt: rc = launch_quilt_any(ctx, p, L); break;
             case kQstream: rc = launch_qstream_any(ctx, p, L); break;
+            case kQhybrid: rc = launch_qhybrid_any(ctx, p, L); break;
             default: rc = launch_generic<256, true>(ctx, p, L); break;
             }
             if (rc != PYLDA_OK) {
