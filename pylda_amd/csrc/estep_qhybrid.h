@@ -6,6 +6,11 @@
 //   tier S   whatever is left               streamed from L2 / Infinity Cache twice per iteration
 //                                           (estep_qstream.h)
 //
+// Tail words (tiers L and S) are processed FUSED, four at a time: a row is loaded into
+// registers once per inner iteration (from LDS or from the table), used for the normaliser
+// partial, the 16-lane sum goes through a tiny LDS exchange, and the same registers then
+// feed the topic sums - one row read and one memory round trip per word per iteration.
+//
 // Every tier uses the same lane grid (lane = 16*g + c: word slot g, topic lane c, topics
 // 2c + 32*jj + {0,1}), so the two reductions and the gamma phase are shared.  The fully
 // streamed kernel moves 2*N_d*K*8 B per inner iteration (3.8 TB per outer iteration at
@@ -29,7 +34,8 @@ struct QhybridLds {
     static constexpr size_t red = 0;                                                   // [W][kQhSpan][17] (tier R uses 4*RWL rows)
     static constexpr size_t rr = red + (size_t)W * kQhSpan * 17 * 8;                   // [W][4*RWL + kQhMaxTail]
     static constexpr size_t nrm = rr + (size_t)W * (4 * RWL + kQhMaxTail) * 8;         // [W][kQhMaxTail]
-    static constexpr size_t sp = nrm + (size_t)W * kQhMaxTail * 8;                     // [W][kTopics]
+    static constexpr size_t cnt = nrm + (size_t)W * kQhMaxTail * 8;                    // [W][kQhMaxTail]
+    static constexpr size_t sp = cnt + (size_t)W * kQhMaxTail * 8;                     // [W][kTopics]
     static constexpr size_t tt = sp + (size_t)W * kTopics * 8;                         // [2][kTopics]
     static constexpr size_t ids = tt + (size_t)2 * kTopics * 8;                        // int [W][kQhMaxTail]
     static constexpr size_t chg = ids + (size_t)W * kQhMaxTail * 4;                    // u64[2]
@@ -60,6 +66,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
     double* red = reinterpret_cast<double*>(smem + L::red);
     double* rr = reinterpret_cast<double*>(smem + L::rr);
     double* nrmv = reinterpret_cast<double*>(smem + L::nrm);
+    double* cntv = reinterpret_cast<double*>(smem + L::cnt);
     double* sp = reinterpret_cast<double*>(smem + L::sp);
     double* tt = reinterpret_cast<double*>(smem + L::tt);
     int* ids = reinterpret_cast<int*>(smem + L::ids);
@@ -91,6 +98,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
     double* myrr = rr + wave * (RNW + kQhMaxTail);        // [0, RNW): tier R, then the tail
     double* myrrT = myrr + RNW;
     double* mynrmT = nrmv + wave * kQhMaxTail;
+    double* mycntT = cntv + wave * kQhMaxTail;
     int* myidsT = ids + wave * kQhMaxTail;
     double* myrows = rows + (size_t)wave * lds_rows_per_wave * ROW;
     const double2* table = reinterpret_cast<const double2*>(p.expElog);
@@ -120,7 +128,10 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
 
     // ---- tail ids, tier L rows, token total (:162) ----
     double local = 0.0;
-    for (int i = lane; i < NTW; i += kWave) myidsT[i] = i < nmineT ? p.term_id[lo + nbT + i] : 0;
+    for (int i = lane; i < NTW; i += kWave) {
+        myidsT[i] = i < nmineT ? p.term_id[lo + nbT + i] : 0;
+        mycntT[i] = i < nmineT ? (double)p.term_ct[lo + nbT + i] : 0.0;
+    }
     for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
     local = wave_sum(local);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -213,42 +224,6 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-        // A(L, S). tail words, kQhSpan at a time
-        for (int base = 0; base < NTW; base += kQhSpan) {
-            const int span = min(kQhSpan, NTW - base);
-            for (int off = 0; off < span; off += 4) {
-                const int i = base + off + g;
-                double part;
-                if (i < NLW)
-                    part = tail_pass_a(reinterpret_cast<const double2*>(myrows + (size_t)i * ROW) + c, tq2);
-                else
-                    part = tail_pass_a(table + (size_t)myidsT[i] * ldk2 + c, tq2);
-                myred[(off + g) * 17 + c] = i < nmineT ? part : 0.0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane < span) {
-                const double* src = myred + lane * 17;
-                double s0 = src[0], s1 = src[1];
-#pragma unroll
-                for (int x = 2; x < 16; x += 2) {
-                    s0 += src[x];
-                    s1 += src[x + 1];
-                }
-                const double s = s0 + s1;
-                const int i = base + lane;
-                const bool live = i < nmineT;
-                if (live && !(s > 1e-280 && s < 1e300)) bad = 1;
-                const double cnt = live ? (double)p.term_ct[lo + nbT + i] : 0.0;
-                mynrmT[i] = s;
-                myrrT[i] = live ? cnt * fast_rcp(s) : 0.0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-
         // B. q[k] over tier R (registers), then the tail rows
         double q[KRL];
         {
@@ -263,26 +238,48 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
                 for (int j = 0; j < KRL; ++j) q[j] = fma(ri, B[i][j], q[j]);
             }
         }
+        // tail words, fused: row -> registers -> normaliser partial -> 16-lane sum -> r -> topic sums
         for (int off = 0; off < NTW; off += 4) {
             const int i = off + g;
-            const double rn = myrrT[i];
-            if (i < NLW) {
-                const double2* row = reinterpret_cast<const double2*>(myrows + (size_t)i * ROW) + c;
+            const double2* row = i < NLW ? reinterpret_cast<const double2*>(myrows + (size_t)i * ROW) + c
+                                         : table + (size_t)myidsT[i] * ldk2 + c;
+            double2 rowv[KRL / 2];
 #pragma unroll
-                for (int jj = 0; jj < KRL / 2; ++jj) {
-                    const double2 b2 = row[16 * jj];
-                    q[2 * jj] = fma(rn, b2.x, q[2 * jj]);
-                    q[2 * jj + 1] = fma(rn, b2.y, q[2 * jj + 1]);
-                }
-            } else {
-                const double2* row = table + (size_t)myidsT[i] * ldk2 + c;
+            for (int jj = 0; jj < KRL / 2; ++jj) rowv[jj] = row[16 * jj];
+            double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-                for (int jj = 0; jj < KRL / 2; ++jj) {
-                    const double2 b2 = row[16 * jj];
-                    q[2 * jj] = fma(rn, b2.x, q[2 * jj]);
-                    q[2 * jj + 1] = fma(rn, b2.y, q[2 * jj + 1]);
-                }
+            for (int jj = 0; jj < KRL / 2; ++jj) {
+                const double2 t2 = tq2[16 * jj];
+                a0 = fma(rowv[jj].x, t2.x, a0);
+                a1 = fma(rowv[jj].y, t2.y, a1);
             }
+            myred[g * 17 + c] = a0 + a1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const double* src = myred + g * 17;              // the 16 partials of this lane group's word
+            double s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];
+#pragma unroll
+            for (int x = 4; x < 16; x += 4) {
+                s0 += src[x];
+                s1 += src[x + 1];
+                s2 += src[x + 2];
+                s3 += src[x + 3];
+            }
+            const double sn = (s0 + s1) + (s2 + s3);
+            const bool live = i < nmineT;
+            if (live && !(sn > 1e-280 && sn < 1e300)) bad = 1;
+            const double rn = live ? mycntT[i] * fast_rcp(sn) : 0.0;
+            if (c == 0) {
+                mynrmT[i] = sn;
+                myrrT[i] = rn;
+            }
+#pragma unroll
+            for (int jj = 0; jj < KRL / 2; ++jj) {
+                q[2 * jj] = fma(rn, rowv[jj].x, q[2 * jj]);
+                q[2 * jj + 1] = fma(rn, rowv[jj].y, q[2 * jj + 1]);
+            }
+            __builtin_amdgcn_wave_barrier();                 // the next chunk reuses myred
         }
         double u[KRL / 2];
 #pragma unroll
@@ -351,7 +348,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
     double shift_term = (word_owner && p.heldout) ? my_cnt * p.shift[p.term_id[lo + my_word]] : 0.0;
     if (word_owner && !p.heldout) p.rfinal[lo + my_word] = r_mine;
     for (int i = lane; i < nmineT; i += kWave) {
-        const double cnt = (double)p.term_ct[lo + nbT + i];
+        const double cnt = mycntT[i];
         term3 = fma(cnt, log(mynrmT[i]), term3);
         if (p.heldout) shift_term = fma(cnt, p.shift[myidsT[i]], shift_term);
         if (!p.heldout) p.rfinal[lo + nbT + i] = myrrT[i];
