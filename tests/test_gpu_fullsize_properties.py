@@ -1,0 +1,103 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent properties (the oracle cannot
+finish 100k documents): conservation laws of the algorithm, fast-path / per-document agreement,
+shard-additivity of the sufficient statistics, bitwise reproducibility, and an oracle spot check
+on documents drawn from the full-size run."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    """cfg 3: synthetic LDA corpus, 100,000 documents, V=50,000, K=128 (bench.py's default workload)."""
+    import torch
+    from pylda_amd import _capi
+    from pylda_amd.corpus import synthetic_lda_corpus_torch
+    ptr, ids, cts = synthetic_lda_corpus_torch(100000, 50000, 128, 200, 1234, device="cuda", chunk=25000)
+    K, V = 128, 50000
+    np.random.seed(0)
+    eta = np.random.gamma(100., 1. / 100., (K, V))
+    alpha = np.full(K, 1.0 / K)
+    ctx = _capi.Context(K, V)
+    corpus = ctx.corpus(ptr, ids, cts)
+    ctx.set_alpha(alpha)
+    ctx.set_eta(eta)
+    ctx.set_option("doc_values", 1)
+    ctx.estep(corpus)
+    ll, _, nlog = ctx.estep_results(corpus)
+    out = dict(ctx=ctx, corpus=corpus, ptr=ptr, ids=ids, cts=cts, K=K, V=V, eta=eta, alpha=alpha, ll=ll,
+               nlog=nlog, gamma=ctx.get_gamma(corpus), sstats=ctx.get_sstats())
+    out["doc_ll"], _, out["iters"] = ctx.get_doc_values(corpus)
+    yield out
+    corpus.close()
+    ctx.close()
+
+
+def test_conservation_laws_at_full_size(cfg3):
+    c = cfg3
+    tokens = c["cts"].sum()
+    assert c["nlog"] == 0
+    # sstats.sum() == #tokens: every phi row sums to one
+    assert abs(c["sstats"].sum() - tokens) < 1e-9 * tokens
+    # column sums of sstats == corpus word counts
+    word_tokens = np.bincount(c["ids"], weights=c["cts"], minlength=c["V"])
+    assert np.max(np.abs(c["sstats"].sum(axis=0) - word_tokens)) < 1e-8 * word_tokens.max()
+    # sum_k gamma_dk - sum alpha == tokens of document d, for every document (:185)
+    doc_tokens = np.add.reduceat(c["cts"].astype(np.float64), c["ptr"][:-1])
+    assert rel_err(c["gamma"].sum(axis=1) - c["alpha"].sum(), doc_tokens) < 1e-12
+    # topic mass: sum_d (gamma_dk - alpha_k) == sum_w sstats[k][w] only at a fixed point; what always holds is
+    # the total: both equal #tokens
+    assert abs((c["gamma"] - c["alpha"]).sum() - tokens) < 1e-9 * tokens
+    assert np.all(c["gamma"] > 0) and np.all(np.isfinite(c["doc_ll"]))
+    assert c["iters"].min() >= 1 and c["iters"].max() <= 50
+    # corpus value == sum of the per-document values
+    assert abs(c["doc_ll"].sum() - c["ll"]) < 1e-11 * abs(c["ll"])
+
+
+def test_fast_path_and_reproducibility_at_full_size(cfg3):
+    c, ctx, corpus = cfg3, cfg3["ctx"], cfg3["corpus"]
+    ctx.set_option("doc_values", 0)                       # what learning() / bench.py run
+    ctx.estep(corpus)
+    ll_fast = ctx.estep_results(corpus)[0]
+    assert abs(ll_fast - c["ll"]) < 1e-11 * abs(c["ll"])
+    assert np.array_equal(ctx.get_sstats(), c["sstats"])  # bitwise: fixed summation order everywhere
+    assert np.array_equal(ctx.get_gamma(corpus), c["gamma"])
+    ctx.set_option("doc_values", 1)
+
+
+def test_shard_additivity_at_full_size(cfg3):
+    """Document sharding (the multi-GPU decomposition): statistics of the shards add up to the whole."""
+    from pylda_amd.corpus import shard_csr
+    c, ctx = cfg3, cfg3["ctx"]
+    total = np.zeros_like(c["sstats"])
+    ll = 0.0
+    for rank in range(2):
+        sp, si, sc, (lo, hi) = shard_csr(c["ptr"], c["ids"], c["cts"], 2, rank)
+        shard = ctx.corpus(sp, si, sc)
+        ctx.estep(shard)
+        ll += ctx.estep_results(shard)[0]
+        total += ctx.get_sstats()
+        assert np.array_equal(ctx.get_gamma(shard), c["gamma"][lo:hi])     # documents are independent
+        shard.close()
+    assert np.max(np.abs(total - c["sstats"])) < 1e-9
+    assert abs(ll - c["ll"]) < 1e-11 * abs(c["ll"])
+
+
+def test_oracle_spot_check_on_full_size_run(cfg3):
+    from oracle import c_oracle
+    c = cfg3
+    rng = np.random.default_rng(0)
+    docs = np.sort(rng.choice(100000, 24, replace=False))
+    order = np.argsort(np.diff(c["ptr"]))
+    docs = np.unique(np.concatenate([docs, order[:2], order[-2:]]))      # plus the shortest and longest
+    from conftest import csr_slice
+    ptr, tid, tct = csr_slice(c["ptr"], c["ids"], c["cts"], docs)
+    ref = c_oracle.e_step(c["alpha"], c["eta"], ptr, tid, tct)
+    same = ref["iters"] == c["iters"][docs]
+    assert same.mean() >= 0.9
+    assert rel_err(c["gamma"][docs][same], ref["gamma"][same]) < 1e-9
+    assert rel_err(c["doc_ll"][docs][same], ref["doc_ll"][same]) < 1e-9
+    assert rel_err(c["doc_ll"][docs], ref["doc_ll"]) < 1e-5                 # the stated bar, all sampled documents
