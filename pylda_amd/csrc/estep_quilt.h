@@ -142,13 +142,10 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
         // A. partial normalisers over this lane's topics -> LDS transpose -> sum over the 16 topic lanes
 #pragma unroll
         for (int i = 0; i < RWL; ++i) {
-            double a0 = B[i][0] * tq[0], a1 = B[i][1] * tq[1];
+            double a0 = B[i][0] * tq[0];                // one chain per word: RWL independent chains
 #pragma unroll
-            for (int j = 2; j < KRL; j += 2) {
-                a0 = fma(B[i][j], tq[j], a0);
-                a1 = fma(B[i][j + 1], tq[j + 1], a1);
-            }
-            myred[(g * RWL + i) * 17 + c] = a0 + a1;
+            for (int j = 1; j < KRL; ++j) a0 = fma(B[i][j], tq[j], a0);
+            myred[(g * RWL + i) * 17 + c] = a0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
