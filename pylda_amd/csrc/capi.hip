@@ -766,8 +766,16 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
         max_terms = std::max(max_terms, n);
     }
     const int64_t nnz = doc_ptr[D];
-    if (max_terms > (1 << 24))
-        return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: a document has %lld distinct terms", (long long)max_terms);
+    {
+        // the most general kernel keeps per-term scalars of one document in LDS
+        const size_t need = generic_lds_layout(ctx->K, (int)std::min<int64_t>(max_terms, 1 << 24),
+                                               tile_stride_for(ctx->K), 256, true).total;
+        if (max_terms > (1 << 24) || need > ctx->lds_limit)
+            return fail(ctx, PYLDA_ERR_INVALID,
+                        "corpus_create: a document has %lld distinct terms; at K=%d the kernels support up to about %lld",
+                        (long long)max_terms, ctx->K,
+                        (long long)((ctx->lds_limit - generic_lds_layout(ctx->K, 0, tile_stride_for(ctx->K), 256, true).total) / 28));
+    }
     if (nnz > INT32_MAX)
         return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: %lld distinct (doc, term) pairs exceed 2^31-1 per device; shard the corpus", (long long)nnz);
     if (nnz > 0 && (!term_id || !term_ct))

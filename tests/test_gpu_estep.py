@@ -338,3 +338,16 @@ def test_error_reporting(capi):
     with pytest.raises(capi.PyldaError):
         capi.Context(0, 5)
     ctx.close()
+    # a document with more distinct terms than any kernel can hold is refused with a clear message
+    big = capi.Context(8, 20000)
+    with pytest.raises(capi.PyldaError) as e:
+        big.corpus(np.array([0, 12000]), np.arange(12000, dtype=np.int32), np.ones(12000, np.int32))
+    assert e.value.status == -1 and "distinct terms" in str(e.value)
+    ok = big.corpus(np.array([0, 4000]), np.arange(4000, dtype=np.int32), np.ones(4000, np.int32))
+    big.set_alpha(np.full(8, 0.2))
+    big.set_eta(np.random.default_rng(0).gamma(100.0, 0.01, (8, 20000)))
+    big.estep(ok)                                           # 4000 distinct terms: generic global-tile kernel
+    ll, _, _ = big.estep_results(ok)
+    assert np.isfinite(ll) and abs(big.get_sstats().sum() - 4000) < 1e-8
+    ok.close()
+    big.close()
