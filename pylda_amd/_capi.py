@@ -63,6 +63,25 @@ def library_path():
     return _LIB_PATH
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    SONAME as the system one).  If this library pulled in the system copy first, a later
+    `import torch` would load the bundled copy as a SECOND runtime and fail with "no
+    ROCm-capable device".  Loading torch's copy first (when torch is installed; torch itself is
+    not imported) makes both resolve to the same runtime, whatever the import order - which is
+    also what lets the context run on torch's streams for the RCCL all-reduce."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+    except Exception:           # no torch, or an unexpected layout: the system runtime is used
+        pass
+
+
 def load():
     """Load libpylda_hip.so; raises RuntimeError when it has not been built."""
     global _lib
@@ -72,6 +91,7 @@ def load():
         raise RuntimeError(
             "pylda_amd: %s is missing - build it with `python -m pylda_amd.build` "
             "(or __graft_entry__.build()).  pylda_amd has no CPU fallback." % _LIB_PATH)
+    _preload_torch_hip_runtime()
     lib = ctypes.CDLL(_LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError => ABI/header mismatch, fail loudly

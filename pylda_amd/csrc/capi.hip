@@ -99,6 +99,7 @@ struct pylda_ctx {
     int force_variant = -1;
     int column_waves = 8;
     int quilt12 = 0;
+    int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
     int doc_values = 1;             // 1: per-document log-likelihoods complete (see EstepParams::want_doc_ll)
     int plan_epoch = 0;
 
@@ -225,6 +226,8 @@ QuiltGeom quilt_geom_for(const pylda_ctx* ctx, int n)
     if (n <= 64) return {8, 2};
     if (n <= 128) return {8, 4};
     if (n <= 192 && ctx->quilt12) return {12, 4};
+    if (n <= 192 && ctx->quilt_odd) return {8, 6};
+    if (n <= 224 && ctx->quilt_odd) return {8, 7};
     if (n <= 256) return {8, 8};
     return {0, 0};
 }
@@ -414,6 +417,7 @@ int launch_quilt_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 #define QUILT_CASE(w_, krl_, rwl_) \
     if (KRL == krl_ && L.rn == w_ * 100 + rwl_) return launch_quilt<w_, krl_, rwl_>(ctx, p, L);
     QUILT_CASE(8, 4, 2) QUILT_CASE(8, 4, 4) QUILT_CASE(8, 4, 8) QUILT_CASE(8, 8, 2) QUILT_CASE(8, 8, 4) QUILT_CASE(8, 8, 8)
+    QUILT_CASE(8, 4, 6) QUILT_CASE(8, 4, 7) QUILT_CASE(8, 8, 6) QUILT_CASE(8, 8, 7)
     QUILT_CASE(12, 4, 4) QUILT_CASE(12, 8, 4)
 #undef QUILT_CASE
     return fail(ctx, PYLDA_ERR_STATE, "no quilt kernel for KRL=%d RWL=%d", KRL, L.rn);
@@ -735,6 +739,9 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         if (value < -1 || value > kQhybrid)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
+        ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "quilt_odd")) {
+        ctx->quilt_odd = value != 0;
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "quilt12")) {
         ctx->quilt12 = value != 0;

@@ -31,8 +31,8 @@ namespace pylda {
 template <int W, int KRL, int RWL>
 struct QuiltLds {
     static constexpr int kTopics = 16 * KRL;
-    static constexpr int kWordsPerWave = 4 * RWL;
-    static constexpr size_t red = 0;                                               // [W][4*RWL][17]
+    static constexpr int kWordsPerWave = RWL <= 2 ? 8 : RWL <= 4 ? 16 : 32;        // 4*RWL padded to a power of two
+    static constexpr size_t red = 0;                                               // [W][kWordsPerWave][17]
     static constexpr size_t rr = red + (size_t)W * kWordsPerWave * 17 * 8;         // [W][4*RWL]
     static constexpr size_t sp = rr + (size_t)W * kWordsPerWave * 8;               // [W][kTopics]
     static constexpr size_t tt = sp + (size_t)W * kTopics * 8;                     // [2][kTopics]
@@ -48,11 +48,12 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     constexpr int NT = kWave * W;
     constexpr int KT = 16 * KRL;            // padded topic count (== ldk)
     constexpr int RNW = 4 * RWL;            // words per wavefront
-    constexpr int LPW = kWave / RNW;        // lanes that finish one word's normaliser
+    constexpr int RNP = L::kWordsPerWave;   // ... padded to a power of two: rows of the LDS transpose
+    constexpr int LPW = kWave / RNP;        // lanes that finish one word's normaliser
     constexpr int PER = 16 / LPW;           // partials each of them adds
     constexpr int QV = KRL / 4;             // topic values per lane after the swap levels
     static_assert(KRL == 4 || KRL == 8, "ldk 64 or 128");
-    static_assert(RWL == 2 || RWL == 4 || RWL == 8, "words per lane");
+    static_assert(RWL >= 2 && RWL <= 8, "words per lane");
     static_assert(KT <= NT, "one thread per topic in the gamma phase");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem + L::red);
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             for (int j = 0; j < KRL; ++j) B[i][j] = 0.0;
         }
     }
-    // the word whose normaliser this lane finishes: nb + lane / LPW
+    // the word whose normaliser this lane finishes: nb + lane / LPW (rows >= RNW are padding)
     const int my_word = nb + lane / LPW;
-    const bool word_live = my_word < N;
+    const bool word_live = lane / LPW < RNW && my_word < N;
     const double my_cnt = word_live ? (double)p.term_ct[lo + my_word] : 0.0;
 
     // ---- total token count (:162) and the invariant sum_k gamma_k ----
@@ -127,8 +128,11 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     double r_mine = 0.0, nrm_mine = 1.0;
     int it = 0;
     int bad = 0;
-    double* myred = red + (size_t)wave * RNW * 17;
-    double* myrr = rr + wave * RNW;
+    double* myred = red + (size_t)wave * RNP * 17;
+    double* myrr = rr + wave * RNP;
+    if constexpr (RNP > RNW) {              // padding rows of the transpose are read but never written
+        for (int x = lane; x < (RNP - RNW) * 17; x += kWave) myred[RNW * 17 + x] = 0.0;
+    }
     while (it < p.max_iter) {                                             // :174
         const int buf = it & 1;
         double tq[KRL];
@@ -174,15 +178,16 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
         // B. q[k] over this lane's words, then over the 4 word groups (two swap levels)
         double q[KRL];
         {
-            const double2* rsrc = reinterpret_cast<const double2*>(myrr + g * RWL);
-            const double2 r01 = rsrc[0];
+            const double* rsrc = myrr + g * RWL;
+            double rl[RWL];
 #pragma unroll
-            for (int j = 0; j < KRL; ++j) q[j] = fma(r01.y, B[1][j], r01.x * B[0][j]);
+            for (int i = 0; i < RWL; ++i) rl[i] = rsrc[i];
 #pragma unroll
-            for (int i = 2; i < RWL; i += 2) {
-                const double2 r2 = rsrc[i / 2];
+            for (int j = 0; j < KRL; ++j) q[j] = fma(rl[1], B[1][j], rl[0] * B[0][j]);
 #pragma unroll
-                for (int j = 0; j < KRL; ++j) q[j] = fma(r2.y, B[i + 1][j], fma(r2.x, B[i][j], q[j]));
+            for (int i = 2; i < RWL; ++i) {
+#pragma unroll
+                for (int j = 0; j < KRL; ++j) q[j] = fma(rl[i], B[i][j], q[j]);
             }
         }
         double u[KRL / 2];

@@ -232,6 +232,42 @@ def make_nips(vb):
           % (len(ptr) - 1, np.diff(ptr).max(), ll, iters.mean()))
 
 
+def make_nips_trace(vb, iterations):
+    """BASELINE.json cfg 5: parsed/nips.88-05, K=500, train = first 2,235 documents, test = last 248
+    (SURVEY 8d), seed 0, `iterations` learning() calls of the reference (about 5 minutes each on one
+    core), then inference() on the test split.  The trace is rewritten after every iteration so that
+    a partial run is still a usable fixture."""
+    tf = tarfile.open(os.path.join(REFERENCE_ROOT, "parsed", "nips.88-05.tar.gz"))
+    docs = [l.strip().lower() for l in tf.extractfile("nips.88-05/doc.dat").read().decode("utf-8").splitlines()]
+    vocab = [l.strip().lower().split()[0] for l in
+             tf.extractfile("nips.88-05/voc.dat").read().decode("utf-8").splitlines() if l.strip()]
+    vocab = list(dict.fromkeys(vocab))
+    train, test = docs[:2235], docs[-248:]
+    K = 500
+    np.random.seed(0)
+    m = vb.VariationalBayes()
+    quiet(m._initialize, train, vocab, K, 1.0 / K, 1.0 / len(vocab))
+    words = np.array([m._index_to_type[i] for i in range(len(vocab))])
+    ptr, tid, tct = csr_of(m._parsed_corpus)
+    parsed_test = quiet(m.parse_data, test)
+    tptr, ttid, ttct = csr_of(parsed_test)
+    joint, alphas, heldout = [], [], []
+    out = os.path.join(HERE, "nips_trace_k500.npz")
+    for it in range(iterations):
+        joint.append(quiet(m.learning))
+        alphas.append(m._alpha_alpha.copy())
+        if (it + 1) % 10 == 0 or it + 1 == iterations:
+            wll, _ = quiet(m.e_step, parsed_test)
+            heldout.append((it + 1, wll))
+        np.savez_compressed(out, words=words, seed=0, K=K, doc_ptr=ptr, term_id=tid.astype(np.int16),
+                            term_ct=tct.astype(np.int16), test_doc_ptr=tptr, test_term_id=ttid.astype(np.int16),
+                            test_term_ct=ttct.astype(np.int16), joint_ll=np.array(joint),
+                            alpha_mean=np.array([a.mean() for a in alphas]), alpha_last=alphas[-1],
+                            heldout=np.array(heldout, dtype=np.float64).reshape(-1, 2),
+                            test_tokens=int(ttct.sum()))
+        print("nips trace iteration %d: %r" % (it + 1, joint[-1]), flush=True)
+
+
 def make_special():
     rng = np.random.default_rng(3)
     x = np.concatenate([
@@ -247,7 +283,8 @@ def make_special():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--trace", type=int, default=3, help="AP K=10 trace length (iterations)")
-    ap.add_argument("--only", default="", help="comma list of: tiny,ap,special,nips")
+    ap.add_argument("--only", default="", help="comma list of: tiny,ap,special,nips,nipstrace")
+    ap.add_argument("--nips-iterations", type=int, default=50)
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
     _, vb = load_reference()
@@ -259,3 +296,5 @@ if __name__ == "__main__":
         make_ap(vb, args.trace)
     if not only or "nips" in only:
         make_nips(vb)
+    if "nipstrace" in only:                 # hours of CPU: only on request
+        make_nips_trace(vb, args.nips_iterations)

@@ -174,3 +174,32 @@ def test_launch_train_and_launch_test_drivers(ap_train, ap_test, tmp_path, capsy
     assert "held-out likelihood of snapshot" in printed
     gamma = np.loadtxt(runs[0] / "test-4")
     assert gamma.shape == (20, 5) and np.all(gamma > 0)
+
+
+def test_nips_k500_trace_and_heldout_likelihood():
+    """BASELINE.json cfg 5 (parsed/nips.88-05, K=500, train = first 2,235 documents, test = last 248):
+    joint log-likelihood per iteration and held-out words log-likelihood every 10 iterations against
+    the reference's own trace (tests/golden/make_golden.py --only nipstrace; as many iterations as the
+    committed fixture holds)."""
+    from pylda_amd.variational_bayes import VariationalBayes
+    g = load_golden("nips_trace_k500.npz")
+    K, V = int(g["K"]), len(g["words"])
+    n_iter = len(g["joint_ll"])
+    np.random.seed(int(g["seed"]))
+    m = VariationalBayes()
+    m._verbose = False
+    m._initialize_parsed(g["doc_ptr"], g["term_id"].astype(np.int32), g["term_ct"].astype(np.int32),
+                         V, K, 1.0 / K, 1.0 / V)            # eta: the same seeded draw as variational_bayes.py:95
+    test = (g["test_doc_ptr"], g["test_term_id"].astype(np.int32), g["test_term_ct"].astype(np.int32))
+    heldout = {int(it): v for it, v in g["heldout"]}
+    for it in range(1, n_iter + 1):
+        joint = m.learning()
+        ref = g["joint_ll"][it - 1]
+        assert abs(joint - ref) < 1e-7 * abs(ref), (it, joint, ref)
+        if it in heldout:
+            wll, gamma = m.e_step(test)
+            assert abs(wll - heldout[it]) < 1e-7 * abs(heldout[it]), (it, wll, heldout[it])
+            assert gamma.shape == (len(test[0]) - 1, K)
+    assert rel_err(m._alpha_alpha, g["alpha_last"]) < 1e-6
+    print("nips K=500: %d iterations match; held-out per-token log-likelihood %.6f"
+          % (n_iter, (heldout[max(heldout)] / int(g["test_tokens"])) if heldout else float("nan")))
