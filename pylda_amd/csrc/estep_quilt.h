@@ -151,9 +151,7 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             for (int j = 1; j < KRL; ++j) a0 = fma(B[i][j], tq[j], a0);
             myred[(g * RWL + i) * 17 + c] = a0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_lds_exchange();
         {
             const int part = lane % LPW;
             const double* src = myred + (lane / LPW) * 17 + part * PER;
@@ -171,9 +169,7 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             r_mine = word_live ? my_cnt * fast_rcp(s) : 0.0;
             if (part == 0) myrr[lane / LPW] = r_mine;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_lds_exchange();
 
         // B. q[k] over this lane's words, then over the 4 word groups (two swap levels)
         double q[KRL];
