@@ -99,6 +99,7 @@ struct pylda_ctx {
     int force_variant = -1;
     int column_waves = 8;
     int quilt12 = 0;
+    int gather_rows = 1;            // whole-row gather kernel for ldk 64 / 128 / 256
     int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
     int doc_values = 1;             // 1: per-document log-likelihoods complete (see EstepParams::want_doc_ll)
     int plan_epoch = 0;
@@ -561,7 +562,18 @@ int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
             hipLaunchKernelGGL(sstats_gather_kernel<32>, grid, dim3(256), 0, ctx->stream, c->d_seg_begin,
                                c->d_seg_end, c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal,
                                c->d_rfinal, ldk, c->d_partial);
-        else
+        else if (ctx->gather_rows && (ldk == 64 || ldk == 128 || ldk == 256)) {
+            const dim3 g1((unsigned)((c->nseg + 3) / 4));
+            if (ldk == 64)
+                hipLaunchKernelGGL(sstats_gather_rows_kernel<1>, g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
+                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial);
+            else if (ldk == 128)
+                hipLaunchKernelGGL(sstats_gather_rows_kernel<2>, g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
+                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial);
+            else
+                hipLaunchKernelGGL(sstats_gather_rows_kernel<4>, g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
+                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial);
+        } else
             hipLaunchKernelGGL(sstats_gather_kernel<64>, grid, dim3(256), 0, ctx->stream, c->d_seg_begin,
                                c->d_seg_end, c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal,
                                c->d_rfinal, ldk, c->d_partial);
@@ -740,6 +752,8 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "gather_rows")) {
+        ctx->gather_rows = value != 0;
     } else if (!strcmp(name, "quilt_odd")) {
         ctx->quilt_odd = value != 0;
         ctx->plan_epoch += 1;

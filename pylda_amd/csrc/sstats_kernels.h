@@ -59,6 +59,44 @@ __global__ __launch_bounds__(256) void sstats_gather_kernel(
     if (sub == 0) partial[(size_t)seg * ldk + k] = acc;
 }
 
+// Whole-row variant for ldk = 64*NCH (NCH = 1, 2, 4): one wavefront accumulates all topics of a
+// segment, so each posting's t_d row is one contiguous ldk*8-byte read and the posting index is
+// loaded once instead of once per 64-topic chunk.
+template <int NCH>
+__global__ __launch_bounds__(256) void sstats_gather_rows_kernel(
+    const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end, int64_t nseg,
+    const int32_t* __restrict__ post_doc, const int32_t* __restrict__ post_pos,
+    const double* __restrict__ tfinal, const double* __restrict__ rfinal, double* __restrict__ partial)
+{
+    constexpr int ldk = 64 * NCH;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t seg = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave;
+    if (seg >= nseg) return;
+    const int64_t b = seg_begin[seg], e = seg_end[seg];
+    double acc0[NCH], acc1[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) acc0[j] = acc1[j] = 0.0;
+    int64_t i = b;
+    for (; i + 1 < e; i += 2) {
+        const double* t0 = tfinal + (size_t)post_doc[i] * ldk + lane;
+        const double* t1 = tfinal + (size_t)post_doc[i + 1] * ldk + lane;
+        const double r0 = rfinal[post_pos[i]], r1 = rfinal[post_pos[i + 1]];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            acc0[j] = fma(r0, t0[64 * j], acc0[j]);
+            acc1[j] = fma(r1, t1[64 * j], acc1[j]);
+        }
+    }
+    if (i < e) {
+        const double* t0 = tfinal + (size_t)post_doc[i] * ldk + lane;
+        const double r0 = rfinal[post_pos[i]];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) acc0[j] = fma(r0, t0[64 * j], acc0[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) partial[(size_t)seg * ldk + lane + 64 * j] = acc0[j] + acc1[j];
+}
+
 // sstats[w][k] = B[w][k] * sum over the word's segments (in order).
 // Also the corpus-level entropy term the document kernels skip on the training
 // fast path:  sum_d sum_n c_n sum_k phi_nk log B[w_n][k] = sum_{w,k} sstats[w][k] * (E_log_eta - shift)[w][k]
