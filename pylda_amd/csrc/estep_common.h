@@ -99,6 +99,15 @@ __device__ __forceinline__ void wave_lds_exchange()
     asm volatile("" ::: "memory");
 }
 
+// Workgroup barrier that orders LDS traffic only: outstanding global loads (a tile gather in
+// flight) are NOT waited for, unlike __syncthreads(), whose release fence drains vmcnt.
+__device__ __forceinline__ void lds_only_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 }  // namespace pylda

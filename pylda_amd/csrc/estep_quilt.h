@@ -74,13 +74,30 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     const int nb = wave * RNW;
     const int wb = nb + g * RWL;            // first word of this lane
 
-    // ---- load the tile ----
+    // ---- small loads first: they must not queue behind the tile gather (vmcnt retires in order) ----
+    int wid[RWL];
+#pragma unroll
+    for (int i = 0; i < RWL; ++i) wid[i] = wb + i < N ? p.term_id[lo + wb + i] : -1;
+    // the word whose normaliser this lane finishes: nb + lane / LPW (rows >= RNW are padding)
+    const int my_word = nb + lane / LPW;
+    const bool word_live = lane / LPW < RNW && my_word < N;
+    const double my_cnt = word_live ? (double)p.term_ct[lo + my_word] : 0.0;
+    double local = 0.0;
+    for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
+    double asum = 0.0;
+    for (int k = lane; k < K; k += kWave) asum += p.alpha[k];
+    const bool topic_thread = tid < KT;
+    const bool topic_live = tid < K;
+    const double alpha_k = topic_live ? p.alpha[tid] : 1.0;
+
+    // ---- the tile gather: issued now, first needed in the inner loop; the set-up below (token
+    // total, psi(sum gamma), first t) runs while it is in flight, which is why the two barriers
+    // of the set-up are raw s_barrier + LDS-only waits (a __syncthreads would wait for the gather) ----
     double B[RWL][KRL];
 #pragma unroll
     for (int i = 0; i < RWL; ++i) {
-        const int n = wb + i;
-        if (n < N) {
-            const double2* row = reinterpret_cast<const double2*>(p.expElog + (size_t)p.term_id[lo + n] * ldk) + c;
+        if (wid[i] >= 0) {
+            const double2* row = reinterpret_cast<const double2*>(p.expElog + (size_t)wid[i] * ldk) + c;
 #pragma unroll
             for (int jj = 0; jj < KRL / 2; ++jj) {
                 const double2 v2 = row[16 * jj];
@@ -92,30 +109,19 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             for (int j = 0; j < KRL; ++j) B[i][j] = 0.0;
         }
     }
-    // the word whose normaliser this lane finishes: nb + lane / LPW (rows >= RNW are padding)
-    const int my_word = nb + lane / LPW;
-    const bool word_live = lane / LPW < RNW && my_word < N;
-    const double my_cnt = word_live ? (double)p.term_ct[lo + my_word] : 0.0;
 
     // ---- total token count (:162) and the invariant sum_k gamma_k ----
-    double local = 0.0;
-    for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
     local = wave_sum(local);
-    double asum = 0.0;
-    for (int k = lane; k < K; k += kWave) asum += p.alpha[k];
     asum = wave_sum(asum);
     if (lane == 0) misc[wave] = local;
     if (tid == 0) chg[0] = chg[1] = 0ull;
-    __syncthreads();
+    lds_only_barrier();
     double total = 0.0;
 #pragma unroll
     for (int w = 0; w < W; ++w) total += misc[w];
     const double psi_total = digamma(asum + total);
 
     // ---- gamma phase state: thread k < KT owns topic k ----
-    const bool topic_thread = tid < KT;
-    const bool topic_live = tid < K;
-    const double alpha_k = topic_live ? p.alpha[tid] : 1.0;
     double gam = alpha_k + total / K;                                     // :165
     double gam_prev = gam;
     double t_mine = 0.0;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
         t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
         tt[tid] = t_mine;
     }
-    __syncthreads();
+    lds_only_barrier();
 
     double r_mine = 0.0, nrm_mine = 1.0;
     int it = 0;
