@@ -1209,15 +1209,18 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* t
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_beta, beta_v, (size_t)V * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     double* d_per_topic = ctx->d_small;          // K
     double* d_alpha_ss = ctx->d_small + K;       // K
-    hipLaunchKernelGGL(mstep_topic_ll_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_eta, K, V, d_per_topic);   // :224 (old eta)
+    hipLaunchKernelGGL(mstep_topic_ll_kernel, dim3(K, kTopicChunks), dim3(256), 0, ctx->stream, ctx->d_eta, K, V,
+                       ctx->d_partial);                                                                             // :224 (old eta)
+    hipLaunchKernelGGL(mstep_topic_ll_finish_kernel, dim3((K + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_partial, K,
+                       d_per_topic);
     hipLaunchKernelGGL(mstep_update_eta_kernel, dim3((K + 31) / 32, (V + 31) / 32), dim3(256), 0, ctx->stream,
                        ctx->d_sstats, ctx->d_beta, K, V, ctx->ldk, ctx->d_eta);                                               // :226
     int nblocks = 0;
     if (alpha_ss_k) {
-        nblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (c->D + 3) / 4));
+        nblocks = (int)std::min<int64_t>(512, std::max<int64_t>(1, (c->D + 3) / 4));
         hipLaunchKernelGGL(mstep_alpha_ss_kernel, dim3(nblocks), dim3(256), (size_t)4 * K * sizeof(double),
                            ctx->stream, c->d_gamma, c->D, K, ctx->d_partial);                                       // :232
-        hipLaunchKernelGGL(column_sum_kernel, dim3((K + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_partial,
+        hipLaunchKernelGGL(column_sum_kernel, dim3((K + 63) / 64), dim3(256), 0, ctx->stream, ctx->d_partial,
                            nblocks, K, d_alpha_ss);                                                                 // :233
     }
     HIP_TRY(ctx, hipGetLastError());

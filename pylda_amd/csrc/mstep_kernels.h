@@ -5,22 +5,44 @@
 
 namespace pylda {
 
-// per_topic[k] = sum_v lnG(eta[k][v]) - lnG(sum_v eta[k][v])       (:224)
+// Topic log-likelihood of the PRE-update eta (:224), two deterministic stages:
+//   part[k][c] = (sum_{v in chunk c} lnG(eta[k][v]), sum_{v in chunk c} eta[k][v])     grid (K, kTopicChunks)
+//   per_topic[k] = sum_c part.lg - lnG(sum_c part.s)
+constexpr int kTopicChunks = 8;
 __global__ __launch_bounds__(256) void mstep_topic_ll_kernel(const double* __restrict__ eta, int K,
-                                                             int V, double* __restrict__ per_topic)
+                                                             int V, double* __restrict__ part)
 {
     __shared__ double scratch[4];
-    const int k = blockIdx.x;
+    const int k = blockIdx.x, chunk = blockIdx.y;
+    const int per = (V + kTopicChunks - 1) / kTopicChunks;
+    const int v0 = chunk * per, v1 = min(V, v0 + per);
     const double* row = eta + (size_t)k * V;
     double lg = 0.0, s = 0.0;
-    for (int v = threadIdx.x; v < V; v += 256) {
+    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
         const double e = row[v];
         lg += lgamma_pos(e);
         s += e;
     }
     lg = block_sum<256>(lg, scratch);
     s = block_sum<256>(s, scratch);
-    if (threadIdx.x == 0) per_topic[k] = lg - lgamma_pos(s);
+    if (threadIdx.x == 0) {
+        part[((size_t)k * kTopicChunks + chunk) * 2] = lg;
+        part[((size_t)k * kTopicChunks + chunk) * 2 + 1] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void mstep_topic_ll_finish_kernel(const double* __restrict__ part, int K,
+                                                                    double* __restrict__ per_topic)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    double lg = 0.0, s = 0.0;
+#pragma unroll
+    for (int c = 0; c < kTopicChunks; ++c) {
+        lg += part[((size_t)k * kTopicChunks + c) * 2];
+        s += part[((size_t)k * kTopicChunks + c) * 2 + 1];
+    }
+    per_topic[k] = lg - lgamma_pos(s);
 }
 
 // eta[k][v] = sstats_wk[v][k] + beta[v]                              (:226)
@@ -69,16 +91,20 @@ __global__ __launch_bounds__(256) void mstep_alpha_ss_kernel(const double* __res
         partial[(size_t)blockIdx.x * K + k] = acc[k] + acc[K + k] + acc[2 * K + k] + acc[3 * K + k];
 }
 
-// out[k] = sum_b partial[b][k]
+// out[k] = sum_b partial[b][k]: 64 topics per workgroup, 4 row groups (b mod 4) summed in a fixed order.
 __global__ __launch_bounds__(256) void column_sum_kernel(const double* __restrict__ partial,
                                                          int nblocks, int K,
                                                          double* __restrict__ out)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    __shared__ double part[4][64];
+    const int kk = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kk;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * K + k];
-    out[k] = s;
+    if (k < K)
+        for (int b = grp; b < nblocks; b += 4) s += partial[(size_t)b * K + k];
+    part[grp][kk] = s;
+    __syncthreads();
+    if (grp == 0 && k < K) out[k] = (part[0][kk] + part[1][kk]) + (part[2][kk] + part[3][kk]);
 }
 
 }  // namespace pylda
