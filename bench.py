@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 import numpy as np
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec)
 CHUNK = 25000
 
 
@@ -215,6 +216,20 @@ def main():
                          "kernel_ms": kernel_avg_ms, "algorithmic_bytes": B},
             "joint_log_likelihood": joint,
         }
+        # the honest companion: the kernel is fp64-VALU / latency bound, not HBM bound.
+        # flops of the inner loops actually executed = sum_d I_d * 4 * N_d * K (two mat-vecs per iteration).
+        try:
+            import ctypes
+            iters = np.empty(D_local, dtype=np.int32)
+            ctx._check(ctx._lib.pylda_get_doc_values(ctx._h, vb._train_corpus._h, None, None,
+                                                     iters.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+            work = float(np.dot(iters.astype(np.float64), np.diff(ptr).astype(np.float64))) * 4.0 * K
+            tflops = work / (kernel_avg_ms * 1e-3) / 1e12 if kernel_avg_ms > 0 else 0.0
+            out["roofline_fp64"] = {"bound": "fp64 vector FMA", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+                                    "flops_per_launch": work, "mean_inner_iterations": float(iters.mean())}
+        except Exception as exc:
+            out["roofline_fp64"] = {"error": str(exc)}
         # ---- CPU baseline + per-document log-likelihood delta on a bounded sample ----
         if not args.no_cpu_baseline:
             alpha = vb._alpha_alpha.copy()
