@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* partial = reinterpret_cast<double*>(smem + L::partial);
     double* red = reinterpret_cast<double*>(smem + L::red);
-    double* chg = reinterpret_cast<double*>(smem + L::chg);
+    unsigned long long* chg = reinterpret_cast<unsigned long long*>(smem + L::chg);   // [2], 2^40 fixed point
     double* misc = reinterpret_cast<double*>(smem + L::misc);
 
     const int tid = threadIdx.x;
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
     const double psi_total = digamma(asum + total);
 
     double tv = 0.0, gam_prev = gam;
+    if (tid == 0) chg[0] = chg[1] = 0ull;          // ordered before the first use by the loop's first barrier
     double r[RN], nrm[RN];
 #pragma unroll
     for (int i = 0; i < RN; ++i) r[i] = nrm[i] = 0.0;
@@ -203,16 +204,19 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
         }
         // gamma update, this lane group's topic
         const double gnew = fma(tv, s, alpha_k);                          // :185
-        double diff = (topic_live && (lane % LP) == 0) ? fabs(gnew - gam) : 0.0;   // :187
+        // sum_k |gamma' - gamma| as a 2^40 fixed-point LDS atomic: integer addition is associative,
+        // so the stop decision is order-independent (and there is no 6-level wavefront reduction
+        // on the serial path)
+        if (topic_live && (lane % LP) == 0) {
+            const double clipped = fmin(fabs(gnew - gam), 1024.0) * 1099511627776.0;   // :187
+            atomicAdd(&chg[buf], (unsigned long long)(clipped + 0.5));
+        }
         gam = gnew;                                                       // :188
-        diff = wave_sum(diff);
-        if (lane == 0) chg[buf * W + wave] = diff;
+        if (tid == 0) chg[buf ^ 1] = 0ull;
         ++it;
         __syncthreads();
-        double change = 0.0;
-#pragma unroll
-        for (int w = 0; w < W; ++w) change += chg[buf * W + w];
-        if (change / K <= p.tol) break;                                   // :189
+        const double change = (double)chg[buf] * (1.0 / 1099511627776.0);
+        if (change <= p.tol * K) break;                                   // :189 (mean <= tol)
     }
 
     bad = __syncthreads_or(bad);
