@@ -28,7 +28,6 @@
 //      barrier
 #pragma once
 #include "estep_common.h"
-#include "estep_slab.h"        // swap32_add / swap16_add / fast_rcp
 #include "special_device.h"
 
 namespace pylda {
@@ -44,8 +43,6 @@ struct ColumnLds {
     static constexpr size_t misc = chg + 16;                                     // [8][W]
     static constexpr size_t total = (misc + (size_t)8 * W * 8 + 15) & ~(size_t)15;
 };
-
-constexpr double kChangeScale = 1099511627776.0;   // 2^40 fixed point for sum |delta gamma|
 
 template <int W, int KR, int RNW>
 __global__ __launch_bounds__(kWave* W) void estep_column_kernel(EstepParams p)
@@ -166,7 +163,7 @@ __global__ __launch_bounds__(kWave* W) void estep_column_kernel(EstepParams p)
             for (int m = 1; m < LPW; m <<= 1) s += __shfl_xor(s, m, kWave);
             nrm_mine = s;
             if (word_live && !(s > 1e-280 && s < 1e300)) bad = 1;
-            r_mine = word_live ? my_cnt * fast_rcp(s) : 0.0;
+            r_mine = word_live ? my_cnt * rcp_newton(s) : 0.0;
             if (part == 0) rr[wave * RNW + lane / LPW] = r_mine;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

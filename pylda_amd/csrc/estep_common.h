@@ -108,6 +108,32 @@ __device__ __forceinline__ void lds_only_barrier()
     asm volatile("" ::: "memory");
 }
 
+// ---- cross-lane helpers shared by the register-resident kernels ----
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// a' = [a.lo32 | b.lo32], b' = [a.hi32 | b.hi32] (halves of the wavefront); returns a' + b'.
+__device__ __forceinline__ double swap32_add(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// the same with 16-lane rows: swaps odd rows of a with even rows of b.
+__device__ __forceinline__ double swap16_add(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+constexpr double kChangeScale = 1099511627776.0;   // 2^40 fixed point for sum_k |delta gamma_k|
+
 __device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 }  // namespace pylda

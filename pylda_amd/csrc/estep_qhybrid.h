@@ -18,8 +18,6 @@
 // that ~6x, which is about where the fp64 work takes over.
 #pragma once
 #include "estep_common.h"
-#include "estep_column.h"      // kChangeScale
-#include "estep_slab.h"        // swap32_add / swap16_add / fast_rcp
 #include "special_device.h"
 
 namespace pylda {
@@ -217,7 +215,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
             for (int m = 1; m < LPW; m <<= 1) s += __shfl_xor(s, m, kWave);
             nrm_mine = s;
             if (word_live && !(s > 1e-280 && s < 1e300)) bad = 1;
-            r_mine = word_live ? my_cnt * fast_rcp(s) : 0.0;
+            r_mine = word_live ? my_cnt * rcp_newton(s) : 0.0;
             if (part == 0) myrr[lane / LPW] = r_mine;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -269,7 +267,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
             const double sn = (s0 + s1) + (s2 + s3);
             const bool live = i < nmineT;
             if (live && !(sn > 1e-280 && sn < 1e300)) bad = 1;
-            const double rn = live ? mycntT[i] * fast_rcp(sn) : 0.0;
+            const double rn = live ? mycntT[i] * rcp_newton(sn) : 0.0;
             if (c == 0) {
                 mynrmT[i] = sn;
                 myrrT[i] = rn;

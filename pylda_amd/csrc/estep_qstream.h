@@ -22,8 +22,6 @@
 // exist for K <= 128.
 #pragma once
 #include "estep_common.h"
-#include "estep_column.h"      // kChangeScale
-#include "estep_slab.h"        // swap32_add / swap16_add / fast_rcp
 #include "special_device.h"
 
 namespace pylda {
@@ -159,7 +157,7 @@ __global__ __launch_bounds__(kWave* W, (KRL <= 16 ? 4 : 2)) void estep_qstream_k
                 if (live && !(s > 1e-280 && s < 1e300)) bad = 1;
                 const double cnt = live ? (double)p.term_ct[lo + nb + i] : 0.0;
                 mynrm[i] = s;
-                myrr[i] = live ? cnt * fast_rcp(s) : 0.0;
+                myrr[i] = live ? cnt * rcp_newton(s) : 0.0;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();

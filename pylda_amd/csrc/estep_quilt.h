@@ -23,7 +23,6 @@
 // Iteration structure, barriers and the gamma phase are those of the column kernel.
 #pragma once
 #include "estep_common.h"
-#include "estep_slab.h"        // swap32_add / swap16_add / fast_rcp
 #include "special_device.h"
 
 namespace pylda {
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             for (int m = 1; m < LPW; m <<= 1) s += __shfl_xor(s, m, kWave);
             nrm_mine = s;
             if (word_live && !(s > 1e-280 && s < 1e300)) bad = 1;
-            r_mine = word_live ? my_cnt * fast_rcp(s) : 0.0;
+            r_mine = word_live ? my_cnt * rcp_newton(s) : 0.0;
             if (part == 0) myrr[lane / LPW] = r_mine;
         }
         wave_lds_exchange();

@@ -40,31 +40,6 @@ struct SlabLds {
     static constexpr size_t total = ((misc + (size_t)8 * W * 8) + 15) & ~(size_t)15;
 };
 
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// a' = [a.lo32 | b.lo32], b' = [a.hi32 | b.hi32] (halves of the wavefront); returns a' + b'.
-__device__ __forceinline__ double swap32_add(double a, double b)
-{
-    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-
-// the same with 16-lane rows: swaps odd rows of a with even rows of b.
-__device__ __forceinline__ double swap16_add(double a, double b)
-{
-    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
-    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-}
-
-__device__ __forceinline__ double fast_rcp(double x) { return rcp_newton(x); }
-
 template <int W, int RK, int RN>
 __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
 {
@@ -161,7 +136,7 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
             const bool live = lane + kWave * i < N;
             if (live && !(s > 1e-280 && s < 1e300)) bad = 1;
             nrm[i] = s;
-            r[i] = live ? cnt[i] * fast_rcp(s) : 0.0;
+            r[i] = live ? cnt[i] * rcp_newton(s) : 0.0;
         }
         // q[k] = sum over this lane's words; s[k] = sum over lanes: two transposing
         // swap levels (topic m pairs with m + RK/2, then with m + RK/4) ...
@@ -208,14 +183,14 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
         // so the stop decision is order-independent (and there is no 6-level wavefront reduction
         // on the serial path)
         if (topic_live && (lane % LP) == 0) {
-            const double clipped = fmin(fabs(gnew - gam), 1024.0) * 1099511627776.0;   // :187
+            const double clipped = fmin(fabs(gnew - gam), 1024.0) * kChangeScale;   // :187
             atomicAdd(&chg[buf], (unsigned long long)(clipped + 0.5));
         }
         gam = gnew;                                                       // :188
         if (tid == 0) chg[buf ^ 1] = 0ull;
         ++it;
         __syncthreads();
-        const double change = (double)chg[buf] * (1.0 / 1099511627776.0);
+        const double change = (double)chg[buf] * (1.0 / kChangeScale);
         if (change <= p.tol * K) break;                                   // :189 (mean <= tol)
     }
 

@@ -6,8 +6,13 @@ in-memory lib2to3 translation) and its associated-press.tar.gz data archive.
 Outputs are small .npz files of inputs and expected outputs (data, no
 source) written next to this script; they are what travels to the GPU box.
 
-    python tests/golden/make_golden.py            # tiny + AP fixtures (~3 min)
-    python tests/golden/make_golden.py --trace N  # + N-iteration AP K=10 trace
+    PYTHONHASHSEED=0 python tests/golden/make_golden.py                   # tiny + AP + nips fixtures
+    PYTHONHASHSEED=0 python tests/golden/make_golden.py --only ap --trace 100   # 100-iteration AP trace (~30 min)
+    PYTHONHASHSEED=0 python tests/golden/make_golden.py --only nipstrace  # nips K=500 trace (~5 min/iteration)
+
+(The reference derives word ids from Python's set() order; PYTHONHASHSEED pins it so that a re-run
+reproduces the committed files.  Every fixture stores the ids it was made with, so the tests do
+not depend on the hash seed.)
 
 Fixtures
   tiny_k2.npz        D=3, V=7, K=2 hand-checkable corpus, training + held-out
