@@ -132,6 +132,39 @@ __device__ __forceinline__ double swap16_add(double a, double b)
     return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
 
+// Lane permutation inside a row of 16 lanes (DPP), on both halves of a double.  CTRL: quad_perm
+// (0x00-0xFF), row_half_mirror 0x141, row_newbcast:L 0x150+L (lane L of each row to all 16 lanes).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int L>
+__device__ __forceinline__ double row_bcast(double v) { return dpp_f64<0x150 + L>(v); }
+
+// out[i] = v of lane i*STEP of the caller's row, i < N
+template <int N, int STEP, int I = 0>
+__device__ __forceinline__ void row_bcast_all(double v, double* out)
+{
+    if constexpr (I < N) {
+        out[I] = row_bcast<I * STEP>(v);
+        row_bcast_all<N, STEP, I + 1>(v, out);
+    }
+}
+
+// sum over aligned groups of LPW (1, 2, 4 or 8) neighbouring lanes; every lane of a group gets it
+template <int LPW>
+__device__ __forceinline__ double lane_group_sum(double s)
+{
+    if constexpr (LPW >= 2) s += dpp_f64<0xB1>(s);      // quad_perm [1,0,3,2]
+    if constexpr (LPW >= 4) s += dpp_f64<0x4E>(s);      // quad_perm [2,3,0,1]
+    if constexpr (LPW >= 8) s += dpp_f64<0x141>(s);     // row_half_mirror: quad 0 <-> quad 1
+    return s;
+}
+
 constexpr double kChangeScale = 1099511627776.0;   // 2^40 fixed point for sum_k |delta gamma_k|
 
 __device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }

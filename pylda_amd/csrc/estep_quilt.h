@@ -30,10 +30,9 @@ namespace pylda {
 template <int W, int KRL, int RWL>
 struct QuiltLds {
     static constexpr int kTopics = 16 * KRL;
-    static constexpr int kWordsPerWave = RWL <= 2 ? 8 : RWL <= 4 ? 16 : 32;        // 4*RWL padded to a power of two
-    static constexpr size_t red = 0;                                               // [W][kWordsPerWave][17]
-    static constexpr size_t rr = red + (size_t)W * kWordsPerWave * 17 * 8;         // [W][4*RWL]
-    static constexpr size_t sp = rr + (size_t)W * kWordsPerWave * 8;               // [W][kTopics]
+    static constexpr int kRowsPerGroup = RWL <= 2 ? 2 : RWL <= 4 ? 4 : 8;          // RWL padded to a power of two
+    static constexpr size_t red = 0;                                               // [W][4*RWL][17]
+    static constexpr size_t sp = red + (size_t)W * 4 * RWL * 17 * 8;               // [W][kTopics]
     static constexpr size_t tt = sp + (size_t)W * kTopics * 8;                     // [2][kTopics]
     static constexpr size_t chg = tt + (size_t)2 * kTopics * 8;                    // u64[2]
     static constexpr size_t misc = chg + 16;                                       // [8][W]
@@ -47,8 +46,7 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     constexpr int NT = kWave * W;
     constexpr int KT = 16 * KRL;            // padded topic count (== ldk)
     constexpr int RNW = 4 * RWL;            // words per wavefront
-    constexpr int RNP = L::kWordsPerWave;   // ... padded to a power of two: rows of the LDS transpose
-    constexpr int LPW = kWave / RNP;        // lanes that finish one word's normaliser
+    constexpr int LPW = 16 / L::kRowsPerGroup;   // lanes (of the word's own 16-lane row) that finish one normaliser
     constexpr int PER = 16 / LPW;           // partials each of them adds
     constexpr int QV = KRL / 4;             // topic values per lane after the swap levels
     static_assert(KRL == 4 || KRL == 8, "ldk 64 or 128");
@@ -56,7 +54,6 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     static_assert(KT <= NT, "one thread per topic in the gamma phase");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem + L::red);
-    double* rr = reinterpret_cast<double*>(smem + L::rr);
     double* sp = reinterpret_cast<double*>(smem + L::sp);
     double* tt = reinterpret_cast<double*>(smem + L::tt);
     unsigned long long* chg = reinterpret_cast<unsigned long long*>(smem + L::chg);
@@ -77,9 +74,11 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     int wid[RWL];
 #pragma unroll
     for (int i = 0; i < RWL; ++i) wid[i] = wb + i < N ? p.term_id[lo + wb + i] : -1;
-    // the word whose normaliser this lane finishes: nb + lane / LPW (rows >= RNW are padding)
-    const int my_word = nb + lane / LPW;
-    const bool word_live = lane / LPW < RNW && my_word < N;
+    // the word whose normaliser this lane finishes, one of its own row's: wb + c / LPW.  Its r then
+    // reaches the 16 lanes that hold the word's tile entries by a DPP row broadcast, not through LDS.
+    const int my_slot = c / LPW;
+    const int my_word = wb + my_slot;
+    const bool word_live = my_slot < RWL && my_word < N;
     const double my_cnt = word_live ? (double)p.term_ct[lo + my_word] : 0.0;
     double local = 0.0;
     for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
@@ -133,11 +132,8 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     double r_mine = 0.0, nrm_mine = 1.0;
     int it = 0;
     int bad = 0;
-    double* myred = red + (size_t)wave * RNP * 17;
-    double* myrr = rr + wave * RNP;
-    if constexpr (RNP > RNW) {              // padding rows of the transpose are read but never written
-        for (int x = lane; x < (RNP - RNW) * 17; x += kWave) myred[RNW * 17 + x] = 0.0;
-    }
+    double* myred = red + (size_t)wave * RNW * 17;
+    const double* mysrc = myred + (g * RWL + (my_slot < RWL ? my_slot : RWL - 1)) * 17 + (c % LPW) * PER;
     while (it < p.max_iter) {                                             // :174
         const int buf = it & 1;
         double tq[KRL];
@@ -158,31 +154,23 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
         }
         wave_lds_exchange();
         {
-            const int part = lane % LPW;
-            const double* src = myred + (lane / LPW) * 17 + part * PER;
-            double s0 = src[0], s1 = PER > 1 ? src[1] : 0.0;
+            double s0 = mysrc[0], s1 = PER > 1 ? mysrc[1] : 0.0;
 #pragma unroll
             for (int x = 2; x < PER; x += 2) {
-                s0 += src[x];
-                s1 += src[x + 1];
+                s0 += mysrc[x];
+                s1 += mysrc[x + 1];
             }
-            double s = s0 + s1;
-#pragma unroll
-            for (int m = 1; m < LPW; m <<= 1) s += __shfl_xor(s, m, kWave);
+            const double s = lane_group_sum<LPW>(s0 + s1);
             nrm_mine = s;
             if (word_live && !(s > 1e-280 && s < 1e300)) bad = 1;
             r_mine = word_live ? my_cnt * rcp_newton(s) : 0.0;
-            if (part == 0) myrr[lane / LPW] = r_mine;
         }
-        wave_lds_exchange();
 
         // B. q[k] over this lane's words, then over the 4 word groups (two swap levels)
         double q[KRL];
         {
-            const double* rsrc = myrr + g * RWL;
             double rl[RWL];
-#pragma unroll
-            for (int i = 0; i < RWL; ++i) rl[i] = rsrc[i];
+            row_bcast_all<RWL, LPW>(r_mine, rl);
 #pragma unroll
             for (int j = 0; j < KRL; ++j) q[j] = fma(rl[1], B[1][j], rl[0] * B[0][j]);
 #pragma unroll
@@ -247,6 +235,8 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
         tq[2 * jj + 1] = t2.y;
     }
     double term1 = 0.0;
+    double rl[RWL];
+    row_bcast_all<RWL, LPW>(r_mine, rl);
     const bool do_term1 = p.heldout || p.want_doc_ll;     // else: taken per corpus from the statistics
 #pragma unroll
     for (int i = 0; i < RWL; ++i) {
@@ -259,10 +249,10 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
                 const double2 g2 = row[16 * jj];
                 gsum2 = fma(g2.y, tq[2 * jj + 1], fma(g2.x, tq[2 * jj], gsum2));
             }
-            term1 = fma(myrr[g * RWL + i], gsum2, term1);
+            term1 = fma(rl[i], gsum2, term1);
         }
     }
-    const bool word_owner = word_live && (lane % LPW) == 0;
+    const bool word_owner = word_live && (c % LPW) == 0;
     double term3 = word_owner ? my_cnt * log(nrm_mine) : 0.0;
     double shift_term = (word_owner && p.heldout) ? my_cnt * p.shift[p.term_id[lo + my_word]] : 0.0;
     double term2 = 0.0, lse_term = 0.0, lgam = 0.0, gsum = 0.0;
