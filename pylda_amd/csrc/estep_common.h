@@ -6,6 +6,7 @@
 namespace pylda {
 
 constexpr int kWave = 64;   // CDNA4 wavefront width
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 // Everything one E-step launch needs.  Tables are WORD-MAJOR (V x K): the
 // reference's E_log_eta[:, ids] column gather (variational_bayes.py:177)

@@ -134,15 +134,28 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     int bad = 0;
     double* myred = red + (size_t)wave * RNW * 17;
     const double* mysrc = myred + (g * RWL + (my_slot < RWL ? my_slot : RWL - 1)) * 17 + (c % LPW) * PER;
-    while (it < p.max_iter) {                                             // :174
-        const int buf = it & 1;
-        double tq[KRL];
+    // The stop test of iteration i (:189) is evaluated AFTER the first half of iteration i+1 has been
+    // issued: the sum of |delta gamma| and the new t are requested together right behind the
+    // barrier, the tile FMAs start as t arrives and the decision rides along (one LDS round trip
+    // and a dependent compare less on the serial path; the speculative half iteration writes only
+    // the transpose scratch).  The test itself is an integer compare on the fixed-point sum:
+    // moved * 2^-40 <= tol * K  <=>  moved <= floor(tol * K * 2^40).
+    const double thresh_f = p.tol * K * kChangeScale;
+    const long long thresh = !(thresh_f >= 0.0) ? -1ll : thresh_f >= 9.2e18 ? 0x7fffffffffffffffll : (long long)thresh_f;
+    long long moved = 0x7fffffffffffffffll;
+    int left = p.max_iter;                  // iterations still allowed (counted down: no reload of the cap per trip)
+    double tq[KRL];
 #pragma unroll
-        for (int jj = 0; jj < KRL / 2; ++jj) {
-            const double2 t2 = reinterpret_cast<const double2*>(tt + buf * KT)[c + 16 * jj];
-            tq[2 * jj] = t2.x;
-            tq[2 * jj + 1] = t2.y;
-        }
+    for (int jj = 0; jj < KRL / 2; ++jj) {
+        const double2 t2 = reinterpret_cast<const double2*>(tt)[c + 16 * jj];
+        tq[2 * jj] = t2.x;
+        tq[2 * jj + 1] = t2.y;
+    }
+#pragma unroll
+    for (int j = 0; j < KRL; ++j) asm volatile("" : "+v"(tq[j]));   // (keeps the in-loop reads at the loop's end: the
+                                                                     //  optimiser would merge both sets at the loop head)
+    for (;;) {                                                            // :174
+        const int buf = it & 1;
 
         // A. partial normalisers over this lane's topics -> LDS transpose -> sum over the 16 topic lanes
 #pragma unroll
@@ -152,6 +165,7 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             for (int j = 1; j < KRL; ++j) a0 = fma(B[i][j], tq[j], a0);
             myred[(g * RWL + i) * 17 + c] = a0;
         }
+        if (moved <= thresh || left <= 0) break;                          // :189 (mean <= tol), :174
         wave_lds_exchange();
         {
             double s0 = mysrc[0], s1 = PER > 1 ? mysrc[1] : 0.0;
@@ -210,9 +224,15 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             if (tid == 0) chg[buf ^ 1] = 0ull;
         }
         ++it;
+        --left;
         __syncthreads();
-        const double change = (double)chg[buf] * (1.0 / kChangeScale);
-        if (change <= p.tol * K) break;                                   // :189 (mean <= tol)
+        moved = (long long)chg[buf];
+#pragma unroll
+        for (int jj = 0; jj < KRL / 2; ++jj) {
+            const double2 t2 = reinterpret_cast<const double2*>(tt + (buf ^ 1) * KT)[c + 16 * jj];
+            tq[2 * jj] = t2.x;
+            tq[2 * jj + 1] = t2.y;
+        }
     }
     const int last = (it - 1) & 1;          // tt[last] holds t of the last executed iteration
 
@@ -227,7 +247,6 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     }
 
     // ---- document terms (:195-204) with the last phi = B t r (see estep_slab.h) ----
-    double tq[KRL];
 #pragma unroll
     for (int jj = 0; jj < KRL / 2; ++jj) {
         const double2 t2 = reinterpret_cast<const double2*>(tt + last * KT)[c + 16 * jj];
