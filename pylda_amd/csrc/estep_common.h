@@ -168,6 +168,28 @@ __device__ __forceinline__ double lane_group_sum(double s)
 
 constexpr double kChangeScale = 1099511627776.0;   // 2^40 fixed point for sum_k |delta gamma_k|
 
+// |delta gamma| (clipped to 1024) as a 2^40 fixed-point integer, rounded to nearest: adding 2^52
+// leaves the integer in the low mantissa bits (one FMA and one AND instead of a 64-bit float -> int
+// conversion sequence on the serial path).
+__device__ __forceinline__ unsigned long long change_fixed(double diff)
+{
+    const double biased = fma(fmin(diff, 1024.0), kChangeScale, 4503599627370496.0);
+    return (unsigned long long)__double_as_longlong(biased) & 0x000fffffffffffffull;
+}
+
+// Forces the N values to be live in registers at this point (loads that produce them are all
+// issued before it; the scheduler otherwise recycles two registers and serialises the round trips).
+template <int N>
+__device__ __forceinline__ void keep_together(double (&v)[N])
+{
+    if constexpr (N == 8)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    else if constexpr (N == 4)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    else
+        for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
 __device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 }  // namespace pylda

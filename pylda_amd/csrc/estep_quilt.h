@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     const double psi_total = digamma(asum + total);
 
     // ---- gamma phase state: thread k < KT owns topic k ----
-    double gam = alpha_k + total / K;                                     // :165
+    double gam = topic_live ? alpha_k + total / K : alpha_k;              // :165 (padding topics never move)
     double gam_prev = gam;
     double t_mine = 0.0;
     if (topic_thread) {
@@ -207,18 +207,21 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
 
         // C. gamma update by the topic threads
         if (topic_thread) {
-            double s0 = sp[tid], s1 = sp[KT + tid];
+            double part[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) part[w] = sp[w * KT + tid];
+            keep_together(part);            // all W reads in flight at once (one LDS round trip, not W/2)
+            double s0 = part[0], s1 = part[1];
 #pragma unroll
             for (int w = 2; w < W; w += 2) {
-                s0 += sp[w * KT + tid];
-                s1 += sp[(w + 1) * KT + tid];
+                s0 += part[w];
+                s1 += part[w + 1];
             }
             const double gnew = fma(t_mine, s0 + s1, alpha_k);            // :185
-            const double diff = topic_live ? fabs(gnew - gam) : 0.0;      // :187
+            const double diff = fabs(gnew - gam);                         // :187
             gam_prev = gam;
             gam = gnew;                                                   // :188
-            const double clipped = fmin(diff, 1024.0) * kChangeScale;
-            atomicAdd(&chg[buf], (unsigned long long)(clipped + 0.5));
+            atomicAdd(&chg[buf], change_fixed(diff));
             t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
             tt[(buf ^ 1) * KT + tid] = t_mine;
             if (tid == 0) chg[buf ^ 1] = 0ull;

@@ -87,29 +87,32 @@ __device__ __forceinline__ double exp_shallow(double x)
 //   psi(y) = log y - 1/(2y) - S(y)   =>   exp(psi(y) - z) = y * exp(-1/(2y) - S(y) - z)
 // with y = x (x >= 10) or y = x + 10 and the recurrence shift
 // sum_{i<10} 1/(x+i) = (2x+9) * sum_{j<5} 1/((x+j)(x+9-j)) added to z.
-// Branch-free (lanes with gamma ~ alpha next to gamma ~ 100 cost nothing extra) and
-// written wide-and-shallow: it runs in the latency-bound gamma phase of the register
-// kernels (two wavefronts active), where dependency depth is the cost, not instruction
-// count - five independent reciprocals instead of one division over a common
-// denominator, Estrin instead of Horner: depth ~23 instead of ~44 fp64 operations.
+// Branch-free (lanes with gamma ~ alpha next to gamma ~ 100 cost nothing extra).  It runs in
+// the gamma phase of the register kernels, where two wavefronts are active: Estrin instead
+// of Horner keeps the dependency chains short, two reciprocals keep the issue count low.
 __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 {
     const bool small = x < 10.0;
     const double y = small ? x + 10.0 : x;
     const double inv = rcp_newton(y);
-    const double i0 = rcp_newton(x * (x + 9.0));
-    const double i1 = rcp_newton((x + 1.0) * (x + 8.0));
-    const double i2 = rcp_newton((x + 2.0) * (x + 7.0));
-    const double i3 = rcp_newton((x + 3.0) * (x + 6.0));
-    const double i4 = rcp_newton((x + 4.0) * (x + 5.0));
-    const double shift = small ? fma(2.0, x, 9.0) * ((i0 + i1) + (i2 + i3) + i4) : 0.0;
+    // the five recurrence reciprocals over ONE common denominator (v_rcp_f64 issues at quarter
+    // rate and each refinement is four dependent FMAs; the gamma phase is issue-bound).  Every
+    // quantity is positive; xs keeps the products finite for lanes that discard the shift.
+    const double xs = small ? x : 10.0;
+    const double q0 = xs * (xs + 9.0), q1 = (xs + 1.0) * (xs + 8.0), q2 = (xs + 2.0) * (xs + 7.0);
+    const double q3 = (xs + 3.0) * (xs + 6.0), q4 = (xs + 4.0) * (xs + 5.0);
+    const double d01 = q0 * q1, d23 = q2 * q3;
+    const double d0123 = d01 * d23;
+    const double num = fma(fma(q2 + q3, d01, (q0 + q1) * d23), q4, d0123);
+    const double recip_sum = num * rcp_newton(d0123 * q4);
+    const double shift = small ? fma(2.0, x, 9.0) * recip_sum : 0.0;
     // S(y) = w (a1 + a2 w + ... + a7 w^6), w = 1/y^2, alternating Bernoulli coefficients
     const double w = inv * inv, w2 = w * w, w4 = w2 * w2;
     const double p01 = fma(w, -1.0 / 120.0, 1.0 / 12.0);
     const double p23 = fma(w, -1.0 / 240.0, 1.0 / 252.0);
     const double p45 = fma(w, -691.0 / 32760.0, 1.0 / 132.0);
-    const double q0 = fma(p23, w2, p01), q1 = fma(1.0 / 12.0, w2, p45);
-    const double series = fma(q1, w4, q0) * w;
+    const double e0 = fma(p23, w2, p01), e1 = fma(1.0 / 12.0, w2, p45);
+    const double series = fma(e1, w4, e0) * w;
     const double tail = fma(-0.5, inv, -series) - (shift + c);     // psi(x) - log(y) - c
     return y * exp_shallow(tail);
 }
