@@ -31,8 +31,12 @@ template <int W, int KRL, int RWL>
 struct QuiltLds {
     static constexpr int kTopics = 16 * KRL;
     static constexpr int kRowsPerGroup = RWL <= 2 ? 2 : RWL <= 4 ? 4 : 8;          // RWL padded to a power of two
-    static constexpr size_t red = 0;                                               // [W][4*RWL][17]
-    static constexpr size_t sp = red + (size_t)W * 4 * RWL * 17 * 8;               // [W][kTopics]
+    // row stride of the normaliser transpose, in doubles: 16-byte aligned rows whose ds_read_b128
+    // pattern below (lane pair / quad / octet of a word reads interleaved 16-byte pieces) is bank
+    // conflict free for the instruction's 16-lane groups (MI355X_MICROARCH.md, LDS)
+    static constexpr int kRedStride = kRowsPerGroup == 8 ? 20 : kRowsPerGroup == 4 ? 24 : 16;
+    static constexpr size_t red = 0;                                               // [W][4*kRowsPerGroup][kRedStride]
+    static constexpr size_t sp = red + (size_t)W * 4 * kRowsPerGroup * kRedStride * 8;   // [W][kTopics]
     static constexpr size_t tt = sp + (size_t)W * kTopics * 8;                     // [2][kTopics]
     static constexpr size_t chg = tt + (size_t)2 * kTopics * 8;                    // u64[2]
     static constexpr size_t misc = chg + 16;                                       // [8][W]
@@ -132,8 +136,9 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     double r_mine = 0.0, nrm_mine = 1.0;
     int it = 0;
     int bad = 0;
-    double* myred = red + (size_t)wave * RNW * 17;
-    const double* mysrc = myred + (g * RWL + (my_slot < RWL ? my_slot : RWL - 1)) * 17 + (c % LPW) * PER;
+    constexpr int RP = L::kRowsPerGroup, RS = L::kRedStride;
+    double* myred = red + (size_t)wave * 4 * RP * RS + (size_t)g * RP * RS;        // this lane group's rows
+    const double2* mysrc = reinterpret_cast<const double2*>(myred + my_slot * RS) + (c % LPW);
     // The stop test of iteration i (:189) is evaluated AFTER the first half of iteration i+1 has been
     // issued: the sum of |delta gamma| and the new t are requested together right behind the
     // barrier, the tile FMAs start as t arrives and the decision rides along (one LDS round trip
@@ -163,17 +168,19 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             double a0 = B[i][0] * tq[0];                // one chain per word: RWL independent chains
 #pragma unroll
             for (int j = 1; j < KRL; ++j) a0 = fma(B[i][j], tq[j], a0);
-            myred[(g * RWL + i) * 17 + c] = a0;
+            myred[i * RS + c] = a0;
         }
         if (moved <= thresh || left <= 0) break;                          // :189 (mean <= tol), :174
         wave_lds_exchange();
         {
-            double s0 = mysrc[0], s1 = PER > 1 ? mysrc[1] : 0.0;
+            double2 s2 = mysrc[0];
 #pragma unroll
-            for (int x = 2; x < PER; x += 2) {
-                s0 += mysrc[x];
-                s1 += mysrc[x + 1];
+            for (int x = 1; x < PER / 2; ++x) {
+                const double2 v2 = mysrc[x * LPW];
+                s2.x += v2.x;
+                s2.y += v2.y;
             }
+            const double s0 = s2.x, s1 = s2.y;
             const double s = lane_group_sum<LPW>(s0 + s1);
             nrm_mine = s;
             if (word_live && !(s > 1e-280 && s < 1e300)) bad = 1;
