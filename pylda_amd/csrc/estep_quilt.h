@@ -159,6 +159,8 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
 #pragma unroll
     for (int j = 0; j < KRL; ++j) asm volatile("" : "+v"(tq[j]));   // (keeps the in-loop reads at the loop's end: the
                                                                      //  optimiser would merge both sets at the loop head)
+    ExpDigammaCoef coef;
+    coef.load();
     for (;;) {                                                            // :174
         const int buf = it & 1;
 
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             gam_prev = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
-            t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
+            t_mine = topic_live ? exp_digamma_minus_with(gam, psi_total, coef) : 0.0;
             tt[(buf ^ 1) * KT + tid] = t_mine;
             if (tid == 0) chg[buf ^ 1] = 0ull;
         }

@@ -90,31 +90,71 @@ __device__ __forceinline__ double exp_shallow(double x)
 // Branch-free (lanes with gamma ~ alpha next to gamma ~ 100 cost nothing extra).  It runs in
 // the gamma phase of the register kernels, where two wavefronts are active: Estrin instead
 // of Horner keeps the dependency chains short, two reciprocals keep the issue count low.
-__device__ __forceinline__ double exp_digamma_minus(double x, double c)
+// Coefficients of exp_digamma_minus that a kernel wants resident in VGPRs for the whole inner
+// loop: 64-bit literals cannot be encoded in VOP3 and the scalar registers are taken by the
+// exp() coefficients, so without this the compiler re-creates them with v_mov in every
+// gamma phase (one issue slot each on a phase that is issue-bound).
+struct ExpDigammaCoef {
+    double nine, ten;
+    double d3, d2, d1, d0;          // D(P)/P = P^4 + 60 P^3 + 1308 P^2 + 12176 P + 40320
+    double n4, n3, n2, n1;          // D'(P)  = 5 P^4 + 240 P^3 + 3924 P^2 + 24352 P + 40320
+    double b1, b2, b3, b4, b5, b6;  // B_2n / 2n, alternating signs folded in
+    __device__ __forceinline__ void load()
+    {
+        nine = 9.0, ten = 10.0;
+        d3 = 60.0, d2 = 1308.0, d1 = 12176.0, d0 = 40320.0;
+        n4 = 5.0, n3 = 240.0, n2 = 3924.0, n1 = 24352.0;
+        b1 = 1.0 / 12.0, b2 = -1.0 / 120.0, b3 = 1.0 / 252.0, b4 = -1.0 / 240.0, b5 = 1.0 / 132.0, b6 = -691.0 / 32760.0;
+        asm volatile("" : "+v"(nine), "+v"(ten), "+v"(d3), "+v"(d2), "+v"(d1), "+v"(d0), "+v"(n4), "+v"(n3));
+        asm volatile("" : "+v"(n2), "+v"(n1), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6));
+    }
+};
+
+template <typename Coef>
+__device__ __forceinline__ double exp_digamma_minus_with(double x, double c, const Coef& k)
 {
-    const bool small = x < 10.0;
-    const double y = small ? x + 10.0 : x;
+    const bool small = x < k.ten;
+    const double y = small ? x + k.ten : x;
     const double inv = rcp_newton(y);
-    // the five recurrence reciprocals over ONE common denominator (v_rcp_f64 issues at quarter
-    // rate and each refinement is four dependent FMAs; the gamma phase is issue-bound).  Every
-    // quantity is positive; xs keeps the products finite for lanes that discard the shift.
-    const double xs = small ? x : 10.0;
-    const double q0 = xs * (xs + 9.0), q1 = (xs + 1.0) * (xs + 8.0), q2 = (xs + 2.0) * (xs + 7.0);
-    const double q3 = (xs + 3.0) * (xs + 6.0), q4 = (xs + 4.0) * (xs + 5.0);
-    const double d01 = q0 * q1, d23 = q2 * q3;
-    const double d0123 = d01 * d23;
-    const double num = fma(fma(q2 + q3, d01, (q0 + q1) * d23), q4, d0123);
-    const double recip_sum = num * rcp_newton(d0123 * q4);
-    const double shift = small ? fma(2.0, x, 9.0) * recip_sum : 0.0;
+    // The ten recurrence terms pair up as 1/(x+j) + 1/(x+9-j) = (2x+9)/(P + c_j) with P = x(x+9)
+    // and c = {0, 8, 14, 18, 20}; their sum is D'(P)/D(P) for D(P) = prod_j (P + c_j), two
+    // polynomials with positive integer coefficients (no cancellation for P > 0) and ONE
+    // reciprocal: v_rcp_f64 issues at quarter rate, and the gamma phase is issue-bound.
+    // xs keeps D finite in lanes that discard the shift.
+    const double xs = fmin(x, k.ten);
+    const double P = xs * (xs + k.nine);
+    double den = P + k.d3;
+    den = fma(den, P, k.d2);
+    den = fma(den, P, k.d1);
+    den = fma(den, P, k.d0) * P;
+    double num = fma(P, k.n4, k.n3);
+    num = fma(num, P, k.n2);
+    num = fma(num, P, k.n1);
+    num = fma(num, P, k.d0);
+    const double recip_sum = num * rcp_newton(den);
+    const double shift = small ? fma(2.0, x, k.nine) * recip_sum : 0.0;
     // S(y) = w (a1 + a2 w + ... + a7 w^6), w = 1/y^2, alternating Bernoulli coefficients
     const double w = inv * inv, w2 = w * w, w4 = w2 * w2;
-    const double p01 = fma(w, -1.0 / 120.0, 1.0 / 12.0);
-    const double p23 = fma(w, -1.0 / 240.0, 1.0 / 252.0);
-    const double p45 = fma(w, -691.0 / 32760.0, 1.0 / 132.0);
-    const double e0 = fma(p23, w2, p01), e1 = fma(1.0 / 12.0, w2, p45);
+    const double p01 = fma(w, k.b2, k.b1);
+    const double p23 = fma(w, k.b4, k.b3);
+    const double p45 = fma(w, k.b6, k.b5);
+    const double e0 = fma(p23, w2, p01), e1 = fma(k.b1, w2, p45);
     const double series = fma(e1, w4, e0) * w;
     const double tail = fma(-0.5, inv, -series) - (shift + c);     // psi(x) - log(y) - c
     return y * exp_shallow(tail);
+}
+
+struct ExpDigammaLiterals {
+    static constexpr double nine = 9.0, ten = 10.0;
+    static constexpr double d3 = 60.0, d2 = 1308.0, d1 = 12176.0, d0 = 40320.0;
+    static constexpr double n4 = 5.0, n3 = 240.0, n2 = 3924.0, n1 = 24352.0;
+    static constexpr double b1 = 1.0 / 12.0, b2 = -1.0 / 120.0, b3 = 1.0 / 252.0, b4 = -1.0 / 240.0, b5 = 1.0 / 132.0,
+                            b6 = -691.0 / 32760.0;
+};
+
+__device__ __forceinline__ double exp_digamma_minus(double x, double c)
+{
+    return exp_digamma_minus_with(x, c, ExpDigammaLiterals());
 }
 
 // ln Gamma(x), x > 0: Stirling series for x >= 12, otherwise shifted up by
