@@ -177,6 +177,15 @@ __device__ __forceinline__ unsigned long long change_fixed(double diff)
     return (unsigned long long)__double_as_longlong(biased) & 0x000fffffffffffffull;
 }
 
+// the same with the 2^52 bias supplied in a (resident) vector register: one VOP3 FMA
+__device__ __forceinline__ unsigned long long change_fixed(double diff, double bias52)
+{
+    double biased;
+    const double clipped = fmin(diff, 1024.0);
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(biased) : "v"(clipped), "s"(kChangeScale), "v"(bias52));
+    return (unsigned long long)__double_as_longlong(biased) & 0x000fffffffffffffull;
+}
+
 // Forces the N values to be live in registers at this point (loads that produce them are all
 // issued before it; the scheduler otherwise recycles two registers and serialises the round trips).
 template <int N>

@@ -161,6 +161,8 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
                                                                      //  optimiser would merge both sets at the loop head)
     ExpDigammaCoef coef;
     coef.load();
+    double bias52 = 4503599627370496.0;
+    asm volatile("" : "+v"(bias52));
     for (;;) {                                                            // :174
         const int buf = it & 1;
 
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             const double diff = fabs(gnew - gam);                         // :187
             gam_prev = gam;
             gam = gnew;                                                   // :188
-            atomicAdd(&chg[buf], change_fixed(diff));
+            atomicAdd(&chg[buf], change_fixed(diff, bias52));
             t_mine = topic_live ? exp_digamma_minus_with(gam, psi_total, coef) : 0.0;
             tt[(buf ^ 1) * KT + tid] = t_mine;
             if (tid == 0) chg[buf ^ 1] = 0ull;

@@ -83,6 +83,44 @@ __device__ __forceinline__ double exp_shallow(double x)
     return ldexp(fma(o1, r8, o0), (int)kf);
 }
 
+// fma(x, m, a) with the multiplier in a scalar and the addend in a vector register, as ONE
+// VOP3 instruction: for a constant addend the compiler otherwise copies it into the
+// accumulator of a v_fmac first (an extra issue slot per term).
+__device__ __forceinline__ double fma_scalar_mul(double x, double m, double a)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(m), "v"(a));
+    return d;
+}
+
+// exp_shallow with its five two-constant terms issued through fma_scalar_mul
+struct ExpCoef {
+    double a2, a3, a4, a5, a6;      // addends 1/4!, 1/6!, 1/8!, 1/10!, 1/12!
+    __device__ __forceinline__ void load()
+    {
+        a2 = 1.0 / 24.0, a3 = 1.0 / 720.0, a4 = 1.0 / 40320.0, a5 = 1.0 / 3628800.0, a6 = 1.0 / 479001600.0;
+        asm volatile("" : "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6));
+    }
+};
+
+__device__ __forceinline__ double exp_shallow_with(double x, const ExpCoef& k)
+{
+    const double kf = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(-kf, 6.93147180369123816490e-01, x);
+    r = fma(-kf, 1.90821492927058770002e-10, r);
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double p0 = r + 1.0;
+    const double p1 = fma(r, 1.0 / 6.0, 0.5);
+    const double p2 = fma_scalar_mul(r, 1.0 / 120.0, k.a2);
+    const double p3 = fma_scalar_mul(r, 1.0 / 5040.0, k.a3);
+    const double p4 = fma_scalar_mul(r, 1.0 / 362880.0, k.a4);
+    const double p5 = fma_scalar_mul(r, 1.0 / 39916800.0, k.a5);
+    const double p6 = fma_scalar_mul(r, 1.0 / 6227020800.0, k.a6);
+    const double q0 = fma(p1, r2, p0), q1 = fma(p3, r2, p2), q2 = fma(p5, r2, p4);
+    const double o0 = fma(q1, r4, q0), o1 = fma(p6, r4, q2);
+    return ldexp(fma(o1, r8, o0), (int)kf);
+}
+
 // exp(psi(x) - c) for x > 0 without the log/exp round trip:
 //   psi(y) = log y - 1/(2y) - S(y)   =>   exp(psi(y) - z) = y * exp(-1/(2y) - S(y) - z)
 // with y = x (x >= 10) or y = x + 10 and the recurrence shift
@@ -99,8 +137,11 @@ struct ExpDigammaCoef {
     double d3, d2, d1, d0;          // D(P)/P = P^4 + 60 P^3 + 1308 P^2 + 12176 P + 40320
     double n4, n3, n2, n1;          // D'(P)  = 5 P^4 + 240 P^3 + 3924 P^2 + 24352 P + 40320
     double b1, b2, b3, b4, b5, b6;  // B_2n / 2n, alternating signs folded in
+    ExpCoef e;
+    __device__ __forceinline__ double exp_of(double x) const { return exp_shallow_with(x, e); }
     __device__ __forceinline__ void load()
     {
+        e.load();
         nine = 9.0, ten = 10.0;
         d3 = 60.0, d2 = 1308.0, d1 = 12176.0, d0 = 40320.0;
         n4 = 5.0, n3 = 240.0, n2 = 3924.0, n1 = 24352.0;
@@ -141,10 +182,11 @@ __device__ __forceinline__ double exp_digamma_minus_with(double x, double c, con
     const double e0 = fma(p23, w2, p01), e1 = fma(k.b1, w2, p45);
     const double series = fma(e1, w4, e0) * w;
     const double tail = fma(-0.5, inv, -series) - (shift + c);     // psi(x) - log(y) - c
-    return y * exp_shallow(tail);
+    return y * k.exp_of(tail);
 }
 
 struct ExpDigammaLiterals {
+    __device__ __forceinline__ double exp_of(double x) const { return exp_shallow(x); }
     static constexpr double nine = 9.0, ten = 10.0;
     static constexpr double d3 = 60.0, d2 = 1308.0, d1 = 12176.0, d0 = 40320.0;
     static constexpr double n4 = 5.0, n3 = 240.0, n2 = 3924.0, n1 = 24352.0;
