@@ -156,6 +156,67 @@ __device__ __forceinline__ void row_bcast_all(double v, double* out)
     }
 }
 
+// q[j] += r(lane L of the caller's row) * b[j]: the row broadcast rides on the FMA's DPP operand
+// (DP-ALU DPP supports row_newbcast; v_fmac_f64 has a DPP form, v_mul_f64 does not), no separate
+// v_mov_dpp pair per word.  The DPP read of r needs two wait states behind the VALU write of r and
+// the compiler's hazard recogniser does not look inside inline assembly: callers put other VALU
+// work (row_bcast_matvec: the first word's plain multiplies) between the two.
+#define PYLDA_DPP_ROW(L) " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n\t"
+template <int L>
+__device__ __forceinline__ void row_bcast_fmac(double (&q)[8], double r, const double (&b)[8])
+{
+    static_assert(L >= 0 && L < 16, "lane of the row");
+#define PYLDA_ROW8(LANE)                                                                                     \
+    "v_fmac_f64_dpp %0, %8, %9" PYLDA_DPP_ROW(LANE) "v_fmac_f64_dpp %1, %8, %10" PYLDA_DPP_ROW(LANE)          \
+    "v_fmac_f64_dpp %2, %8, %11" PYLDA_DPP_ROW(LANE) "v_fmac_f64_dpp %3, %8, %12" PYLDA_DPP_ROW(LANE)         \
+    "v_fmac_f64_dpp %4, %8, %13" PYLDA_DPP_ROW(LANE) "v_fmac_f64_dpp %5, %8, %14" PYLDA_DPP_ROW(LANE)         \
+    "v_fmac_f64_dpp %6, %8, %15" PYLDA_DPP_ROW(LANE) "v_fmac_f64_dpp %7, %8, %16" PYLDA_DPP_ROW(LANE)
+#define PYLDA_ROW8_CASE(LANE)                                                                                \
+    if constexpr (L == LANE)                                                                                 \
+        asm(PYLDA_ROW8(LANE)                                                                                 \
+            : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) \
+            : "v"(r), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
+    PYLDA_ROW8_CASE(0) PYLDA_ROW8_CASE(1) PYLDA_ROW8_CASE(2) PYLDA_ROW8_CASE(3) PYLDA_ROW8_CASE(4) PYLDA_ROW8_CASE(5)
+    PYLDA_ROW8_CASE(6) PYLDA_ROW8_CASE(7) PYLDA_ROW8_CASE(8) PYLDA_ROW8_CASE(9) PYLDA_ROW8_CASE(10) PYLDA_ROW8_CASE(11)
+    PYLDA_ROW8_CASE(12) PYLDA_ROW8_CASE(13) PYLDA_ROW8_CASE(14) PYLDA_ROW8_CASE(15)
+#undef PYLDA_ROW8_CASE
+#undef PYLDA_ROW8
+}
+
+template <int L>
+__device__ __forceinline__ void row_bcast_fmac(double (&q)[4], double r, const double (&b)[4])
+{
+    static_assert(L >= 0 && L < 16, "lane of the row");
+#define PYLDA_ROW4(LANE)                                                                                     \
+    "v_fmac_f64_dpp %0, %4, %5" PYLDA_DPP_ROW(LANE) "v_fmac_f64_dpp %1, %4, %6" PYLDA_DPP_ROW(LANE)           \
+    "v_fmac_f64_dpp %2, %4, %7" PYLDA_DPP_ROW(LANE) "v_fmac_f64_dpp %3, %4, %8" PYLDA_DPP_ROW(LANE)
+#define PYLDA_ROW4_CASE(LANE)                                                                                \
+    if constexpr (L == LANE)                                                                                 \
+        asm(PYLDA_ROW4(LANE)                                                                                 \
+            : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3])                                                 \
+            : "v"(r), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    PYLDA_ROW4_CASE(0) PYLDA_ROW4_CASE(1) PYLDA_ROW4_CASE(2) PYLDA_ROW4_CASE(3) PYLDA_ROW4_CASE(4) PYLDA_ROW4_CASE(5)
+    PYLDA_ROW4_CASE(6) PYLDA_ROW4_CASE(7) PYLDA_ROW4_CASE(8) PYLDA_ROW4_CASE(9) PYLDA_ROW4_CASE(10) PYLDA_ROW4_CASE(11)
+    PYLDA_ROW4_CASE(12) PYLDA_ROW4_CASE(13) PYLDA_ROW4_CASE(14) PYLDA_ROW4_CASE(15)
+#undef PYLDA_ROW4_CASE
+#undef PYLDA_ROW4
+}
+
+// q[j] = sum_i r(lane i*STEP of the row) * B[i][j]
+template <int RWL, int STEP, int KRL, int I = 0>
+__device__ __forceinline__ void row_bcast_matvec(double (&q)[KRL], double r, const double (&B)[RWL][KRL])
+{
+    if constexpr (I == 0) {
+        const double r0 = row_bcast<0>(r);
+#pragma unroll
+        for (int j = 0; j < KRL; ++j) q[j] = r0 * B[0][j];
+        row_bcast_matvec<RWL, STEP, KRL, 1>(q, r, B);
+    } else if constexpr (I < RWL) {
+        row_bcast_fmac<I * STEP>(q, r, B[I]);
+        row_bcast_matvec<RWL, STEP, KRL, I + 1>(q, r, B);
+    }
+}
+
 // sum over aligned groups of LPW (1, 2, 4 or 8) neighbouring lanes; every lane of a group gets it
 template <int LPW>
 __device__ __forceinline__ double lane_group_sum(double s)

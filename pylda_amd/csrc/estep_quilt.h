@@ -193,17 +193,7 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
 
         // B. q[k] over this lane's words, then over the 4 word groups (two swap levels)
         double q[KRL];
-        {
-            double rl[RWL];
-            row_bcast_all<RWL, LPW>(r_mine, rl);
-#pragma unroll
-            for (int j = 0; j < KRL; ++j) q[j] = fma(rl[1], B[1][j], rl[0] * B[0][j]);
-#pragma unroll
-            for (int i = 2; i < RWL; ++i) {
-#pragma unroll
-                for (int j = 0; j < KRL; ++j) q[j] = fma(rl[i], B[i][j], q[j]);
-            }
-        }
+        row_bcast_matvec<RWL, LPW>(q, r_mine, B);      // r of word i sits in lane i*LPW of this lane's row
         double u[KRL / 2];
 #pragma unroll
         for (int m = 0; m < KRL / 2; ++m) u[m] = swap32_add(q[m], q[m + KRL / 2]);
