@@ -27,6 +27,7 @@
 #include "estep_quilt.h"
 #include "estep_qstream.h"
 #include "estep_qhybrid.h"
+#include "estep_qwide.h"
 #include "mstep_kernels.h"
 #include "prepare_kernels.h"
 #include "sstats_kernels.h"
@@ -46,7 +47,8 @@ enum Variant : int {
     kColumn = 5,        // tile in registers, topic-major lanes (estep_column.h)
     kQuilt = 6,         // tile in registers, 4 x 16 word-group x topic lanes (estep_quilt.h)
     kQstream = 7,       // tile streamed from L2 twice per iteration, quilt lanes (estep_qstream.h)
-    kQhybrid = 8        // tile split over registers / LDS / streamed remainder (estep_qhybrid.h)
+    kQhybrid = 8,       // tile split over registers / LDS / streamed remainder (estep_qhybrid.h)
+    kQwide = 9          // the same three tiers on a 2 x 32 lane grid with prefetched tail rows (estep_qwide.h)
 };
 
 struct Launch {
@@ -240,6 +242,13 @@ bool qhybrid_ok(const pylda_ctx* ctx, int n)
     return ctx->ldk % 64 == 0 && ctx->ldk <= 256 && n <= 128 + 8 * (kQhMaxTail - 4) && ctx->lds_limit >= 160 * 1024;
 }
 
+// Wide tiered kernel: ldk 128 / 192 / 256, documents up to 624 distinct terms.
+bool qwide_ok(const pylda_ctx* ctx, int n)
+{
+    return (ctx->ldk == 128 || ctx->ldk == 192 || ctx->ldk == 256) && n <= kQwRegWords + 8 * (kQwMaxTail - 2) &&
+           ctx->lds_limit >= 160 * 1024;
+}
+
 // Streaming quilt kernel: any ldk that is a multiple of 64 up to 512, documents up to 1000 terms.
 bool qstream_ok(const pylda_ctx* ctx, int n) { return ctx->ldk % 64 == 0 && ctx->ldk <= 512 && n <= 1000; }
 
@@ -257,6 +266,10 @@ int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
     if ((ctx->force_variant < 0 || ctx->force_variant == kSlab) && slab_geom_for(ctx, n).W > 0) {
         *lds_bytes = 0;
         return kSlab;
+    }
+    if ((ctx->force_variant < 0 || ctx->force_variant == kQwide) && qwide_ok(ctx, n)) {
+        *lds_bytes = 0;
+        return kQwide;
     }
     if ((ctx->force_variant < 0 || ctx->force_variant == kQhybrid) && qhybrid_ok(ctx, n)) {
         *lds_bytes = 0;
@@ -450,6 +463,31 @@ int launch_qhybrid(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * 8), lds, ctx->stream, p, rows_per_wave);
     HIP_TRY(ctx, hipGetLastError());
     return PYLDA_OK;
+}
+
+template <int JJ>
+int launch_qwide(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    using Lds = QwideLds<8, JJ>;
+    auto kern = estep_qwide_kernel<8, JJ>;
+    const size_t limit = 160 * 1024;
+    const int rows_per_wave = std::min(kQwMaxTail, Lds::rows_that_fit(limit) / 8) & ~1;
+    const size_t lds = Lds::fixed_total + (size_t)8 * rows_per_wave * Lds::kRowDoubles * 8;
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * 8), lds, ctx->stream, p, rows_per_wave);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+int launch_qwide_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    switch (ctx->ldk / 64) {
+    case 2: return launch_qwide<2>(ctx, p, L);
+    case 3: return launch_qwide<3>(ctx, p, L);
+    case 4: return launch_qwide<4>(ctx, p, L);
+    }
+    return fail(ctx, PYLDA_ERR_STATE, "no wide tiered kernel for table stride %d", ctx->ldk);
 }
 
 int launch_qhybrid_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
@@ -748,7 +786,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kQhybrid)
+        if (value < -1 || value > kQwide)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
@@ -1019,6 +1057,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kQuilt: rc = launch_quilt_any(ctx, p, L); break;
             case kQstream: rc = launch_qstream_any(ctx, p, L); break;
             case kQhybrid: rc = launch_qhybrid_any(ctx, p, L); break;
+            case kQwide: rc = launch_qwide_any(ctx, p, L); break;
             default: rc = launch_generic<256, true>(ctx, p, L); break;
             }
             if (rc != PYLDA_OK) {

@@ -202,6 +202,15 @@ __device__ __forceinline__ void row_bcast_fmac(double (&q)[4], double r, const d
 #undef PYLDA_ROW4
 }
 
+// other row lengths: broadcast first, plain FMAs
+template <int L, int KRL>
+__device__ __forceinline__ void row_bcast_fmac(double (&q)[KRL], double r, const double (&b)[KRL])
+{
+    const double rb = row_bcast<L>(r);
+#pragma unroll
+    for (int j = 0; j < KRL; ++j) q[j] = fma(rb, b[j], q[j]);
+}
+
 // q[j] = sum_i r(lane i*STEP of the row) * B[i][j]
 template <int RWL, int STEP, int KRL, int I = 0>
 __device__ __forceinline__ void row_bcast_matvec(double (&q)[KRL], double r, const double (&B)[RWL][KRL])

@@ -108,7 +108,7 @@ def test_ap_heldout_k10_matches_reference_goldens(capi, ap_test):
     assert abs(out["words_log_likelihood"] - float(g["corpus_words_ll"])) < 1e-9 * abs(float(g["corpus_words_ll"]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_every_kernel_variant_agrees(capi, ap_train, variant):
     g = ap_train
     docs = list(range(0, 2000, 10))
@@ -175,7 +175,8 @@ def random_corpus(rng, D, V, mean_len, zipf=1.1):
 
 @pytest.mark.parametrize("K,V,D,mean_len", [(128, 2000, 48, 200), (64, 500, 64, 40), (500, 800, 12, 300),
                                             (3, 50, 100, 5), (256, 3000, 16, 250), (1, 20, 5, 10),
-                                            (256, 4000, 40, 420), (200, 2500, 24, 700), (130, 3000, 30, 1200)])
+                                            (256, 4000, 40, 420), (200, 2500, 24, 700), (130, 3000, 30, 1200),
+                                            (192, 3000, 24, 300), (150, 2500, 20, 170), (256, 3000, 12, 100)])
 def test_random_corpora_against_c_oracle(capi, K, V, D, mean_len):
     from oracle import c_oracle
     rng = np.random.default_rng(K * 1000 + V)
@@ -209,7 +210,7 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
     ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
     gen = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 1)])
     held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
-    for variant in (4, 5, 6, 7, 8):              # slab, column, quilt (register tiles), streaming, hybrid
+    for variant in (4, 5, 6, 7, 8, 9):           # slab, column, quilt (register tiles), streaming, hybrid, wide tiered
         out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
         check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
         assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
@@ -224,7 +225,7 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6, 7, 8, 9])
 def test_training_fast_path_corpus_likelihood(capi, ap_train, variant):
     """Option doc_values=0 (what learning() uses): the corpus-level document_log_likelihood must equal
     the sum of the complete per-document values, and the reference's own corpus value."""
