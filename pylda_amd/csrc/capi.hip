@@ -465,11 +465,11 @@ int launch_qhybrid(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     return PYLDA_OK;
 }
 
-template <int JJ>
+template <int JJ, bool MULTI>
 int launch_qwide(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
     using Lds = QwideLds<8, JJ>;
-    auto kern = estep_qwide_kernel<8, JJ>;
+    auto kern = estep_qwide_kernel<8, JJ, MULTI>;
     const size_t limit = 160 * 1024;
     const int rows_per_wave = std::min(kQwMaxTail, Lds::rows_that_fit(limit) / 8) & ~1;
     const size_t lds = Lds::fixed_total + (size_t)8 * rows_per_wave * Lds::kRowDoubles * 8;
@@ -482,10 +482,11 @@ int launch_qwide(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 
 int launch_qwide_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
+    const bool multi = L.n_cap > kQwRegWords + 8 * 16;     // more than one round of tail steps per wavefront
     switch (ctx->ldk / 64) {
-    case 2: return launch_qwide<2>(ctx, p, L);
-    case 3: return launch_qwide<3>(ctx, p, L);
-    case 4: return launch_qwide<4>(ctx, p, L);
+    case 2: return multi ? launch_qwide<2, true>(ctx, p, L) : launch_qwide<2, false>(ctx, p, L);
+    case 3: return multi ? launch_qwide<3, true>(ctx, p, L) : launch_qwide<3, false>(ctx, p, L);
+    case 4: return multi ? launch_qwide<4, true>(ctx, p, L) : launch_qwide<4, false>(ctx, p, L);
     }
     return fail(ctx, PYLDA_ERR_STATE, "no wide tiered kernel for table stride %d", ctx->ldk);
 }

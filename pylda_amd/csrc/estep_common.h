@@ -117,6 +117,14 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// a value known to be the same in every lane, moved to scalar registers
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // a' = [a.lo32 | b.lo32], b' = [a.hi32 | b.hi32] (halves of the wavefront); returns a' + b'.
 __device__ __forceinline__ double swap32_add(double a, double b)
 {
@@ -131,6 +139,20 @@ __device__ __forceinline__ double swap16_add(double a, double b)
     const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
     const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
     return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression
+template <int I>
+struct StaticIndex {
+    static constexpr int value = I;
+};
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(StaticIndex<I>());
+        static_for<N, I + 1>(f);
+    }
 }
 
 // Lane permutation inside a row of 16 lanes (DPP), on both halves of a double.  CTRL: quad_perm

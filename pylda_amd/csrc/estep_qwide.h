@@ -7,24 +7,27 @@
 //   => a table row is read as 32-lane x 512-byte contiguous pieces (16-byte loads)
 //
 // With 32 topic lanes a K = 256 row costs 8 registers per lane (the 16-lane quilt of
-// estep_qhybrid.h needs 16): t, the topic sums and a streamed row each shrink by half, which
-// is what leaves room to PREFETCH the next tail rows while the current ones are used.
+// estep_qhybrid.h needs 16): t, the topic sums and a tail row each shrink by half, which is
+// what leaves room for two row buffers that are re-filled two steps ahead.
 //
 // The tile is split in three tiers (as in estep_qhybrid.h):
 //   tier R   the first 16*8 = 128 words        in VGPRs   B[8][KRL]
 //   tier L   the next  NL words                in LDS     whole rows, loaded once per document
-//   tier S   whatever is left                  streamed from L2 / Infinity Cache once per iteration
+//   tier S   whatever is left                  streamed from L2 / Infinity Cache twice per iteration
 //
 // Per inner iteration:
 //   A(R)  in-lane sum_k B t per word -> LDS transpose (32 partials per word, 16-byte aligned rows,
 //         conflict-free ds_read_b128) -> four lanes per word finish the normaliser (DPP inside the
 //         row, one permlane16 swap across the group's two rows) -> r
-//   B(R)  q[k] += r B with r broadcast inside the row by the FMA's DPP operand
-//   tail  two words per step (one per group), FUSED: row -> registers (from LDS or the table, the
-//         next step's rows already requested) -> partial -> 32-lane all-reduce by DPP + one swap
-//         (no LDS round trip) -> r -> q[k] += r row
-//   then one permlane32 swap level over the two groups, per-wavefront partials to LDS, barrier,
-//   gamma phase on ldk topic threads (estep_quilt.h), barrier.
+//   tail  (two words per step, one per group; a round is up to 8 steps = 16 words per wavefront,
+//         handled like a second tier R whose rows come from memory)
+//         pass 1: row -> in-lane partial -> the same transpose area; finish: normalisers and r of
+//         the round's words side by side, r kept in LDS; B(R): q[k] = sum r B with r broadcast
+//         inside the row by the FMA's DPP operand; pass 2: row again -> q[k] += r row
+//   then one permlane32 swap level over the two groups, per-wavefront partials to LDS (in the
+//   transpose area), barrier, gamma phase on ldk topic threads (estep_quilt.h; its state lives in
+//   LDS and its coefficients in scalar registers: the K = 256 instance is at the 256-VGPR limit),
+//   barrier.
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
@@ -46,7 +49,8 @@ struct QwideLds {
     static constexpr size_t nrm = rr + (size_t)W * kQwMaxTail * 8;                     // [W][kQwMaxTail]
     static constexpr size_t cnt = nrm + (size_t)W * kQwMaxTail * 8;                    // [W][kQwMaxTail]
     static constexpr size_t tt = cnt + (size_t)W * kQwMaxTail * 8;                     // [2][kTopics]
-    static constexpr size_t ids = tt + (size_t)2 * kTopics * 8;                        // int [W][kQwMaxTail]
+    static constexpr size_t gst = tt + (size_t)2 * kTopics * 8;                        // [2][kTopics]: alpha, previous gamma
+    static constexpr size_t ids = gst + (size_t)2 * kTopics * 8;                       // int [W][kQwMaxTail]
     static constexpr size_t chg = ids + (size_t)W * kQwMaxTail * 4;                    // u64[2]
     static constexpr size_t misc = chg + 16;                                           // [8][W]
     static constexpr size_t rows = (misc + (size_t)8 * W * 8 + 15) & ~(size_t)15;      // tier L rows start here
@@ -67,7 +71,9 @@ __device__ __forceinline__ double group32_sum(double s)
     return swap16_add(s, s);    // rows 2g and 2g+1
 }
 
-template <int W, int JJ>
+// MULTI: documents with more than 8 tail steps per wavefront (N > 256) loop over rounds; the
+// single-round instance lets t die after pass 1 (the kernel is at the register limit at K = 256).
+template <int W, int JJ, bool MULTI>
 __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, int lds_rows_per_wave)
 {
     using L = QwideLds<W, JJ>;
@@ -87,6 +93,8 @@ __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, in
     double* nrmv = reinterpret_cast<double*>(smem + L::nrm);
     double* cntv = reinterpret_cast<double*>(smem + L::cnt);
     double* tt = reinterpret_cast<double*>(smem + L::tt);
+    double* alphaS = reinterpret_cast<double*>(smem + L::gst);            // gamma-phase state kept in LDS, not in
+    double* gprevS = alphaS + KT;                                         // registers (read where the partial sums are)
     int* ids = reinterpret_cast<int*>(smem + L::ids);
     unsigned long long* chg = reinterpret_cast<unsigned long long*>(smem + L::chg);
     double* misc = reinterpret_cast<double*>(smem + L::misc);
@@ -181,14 +189,13 @@ __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, in
     double total = 0.0;
 #pragma unroll
     for (int w = 0; w < W; ++w) total += misc[w];
-    const double psi_total = digamma(asum + total);
+    const double psi_total = uniform_f64(digamma(asum + total));          // the same in every lane: scalar registers
 
     double gam = topic_live ? alpha_k + total / K : alpha_k;              // :165 (padding topics never move)
-    double gam_prev = gam;
-    double t_mine = 0.0;
     if (topic_thread) {
-        t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
-        tt[tid] = t_mine;
+        tt[tid] = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
+        alphaS[tid] = alpha_k;
+        gprevS[tid] = gam;
     }
     __syncthreads();                        // also: the tier L rows are in place (their global loads drained)
 
@@ -198,7 +205,8 @@ __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, in
     const double2* mysrc = reinterpret_cast<const double2*>(myred + (g * RWL + my_slot) * RS) + my_part;
     // the stop test of iteration i rides behind the first half of iteration i+1 (estep_quilt.h)
     const double thresh_f = p.tol * K * kChangeScale;
-    const long long thresh = !(thresh_f >= 0.0) ? -1ll : thresh_f >= 9.2e18 ? 0x7fffffffffffffffll : (long long)thresh_f;
+    const long long thresh = __double_as_longlong(uniform_f64(__longlong_as_double(
+        !(thresh_f >= 0.0) ? -1ll : thresh_f >= 9.2e18 ? 0x7fffffffffffffffll : (long long)thresh_f)));
     long long moved = 0x7fffffffffffffffll;
     int left = p.max_iter;
     double tq[KRL];
@@ -211,23 +219,75 @@ __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, in
 #pragma unroll
     for (int j = 0; j < KRL; ++j) asm volatile("" : "+v"(tq[j]));
 
-    // one tail step's rows: words off + g of this wavefront's tail, from LDS (tier L) or the table (tier S)
-    auto load_rows = [&](int off, double2 (&rowv)[JJ], double& cnt) {
-        const int i = off + g;
-        cnt = mycntT[i];
-        if (off < NLW) {
-            const double2* row = reinterpret_cast<const double2*>(myrows + (size_t)i * ROW) + c;
+    // Tail steps (two words each: one per group), streamed steps first.  A ROUND is up to eight
+    // steps = 16 words per wavefront, handled like a second tier R whose rows come from memory:
+    //   pass 1  row -> in-lane partial -> transpose area
+    //   finish  four lanes per word: normaliser, r (kept in LDS for pass 2 and the epilogue)
+    //   pass 2  row again -> q += r row
+    // so the reduction and reciprocal chains of a round's words run side by side, and a step is
+    // 8 + 8 FMAs and a handful of address instructions.  Rows go through two alternating register
+    // buffers, each re-filled two steps ahead; the first two rows of an iteration (streamed ones,
+    // when the document has any) are requested before the tier R work.  cfg 4 (~70 tail words) is
+    // one round.
+    typedef const f64x2 __attribute__((address_space(3)))* lds_row_ptr;
+    const int nS = (NTW - NLW) / 2, nsteps = NTW / 2;
+    // (a generic pointer into LDS carries the LDS byte offset in its low 32 bits)
+    const unsigned myrows_lds = (unsigned)(uintptr_t)(myrows + 2 * c);
+    auto tail_index = [&](int st) { return (st < nS ? NLW + 2 * st : 2 * (st - nS)) + g; };
+    auto fetch_streamed = [&](int st, f64x2 (&rowv)[JJ]) {     // tier S: from the table (L2 / Infinity Cache)
+        const f64x2* row = reinterpret_cast<const f64x2*>(table + (size_t)myidsT[NLW + 2 * st + g] * ldk2 + c);
 #pragma unroll
-            for (int jj = 0; jj < JJ; ++jj) rowv[jj] = row[32 * jj];
-        } else {
-            const double2* row = table + (size_t)myidsT[i] * ldk2 + c;
+        for (int jj = 0; jj < JJ; ++jj) rowv[jj] = row[32 * jj];
+    };
+    auto fetch_resident = [&](int st, f64x2 (&rowv)[JJ]) {     // tier L: explicit LDS address space (ds_read_b128)
+        lds_row_ptr row = (lds_row_ptr)(uintptr_t)(myrows_lds + (unsigned)(2 * (st - nS) + g) * (ROW * 8));
 #pragma unroll
-            for (int jj = 0; jj < JJ; ++jj) rowv[jj] = row[32 * jj];
+        for (int jj = 0; jj < JJ; ++jj) rowv[jj] = row[32 * jj];
+    };
+    // steps [lo, hi) of ONE tier through the two alternating buffers; each buffer is re-filled two
+    // steps ahead and the loop body issues a fixed number of loads (so the compiler's wait counts
+    // are exact: a step waits for its own row only).  `primed`: r0 / r1 already hold steps lo, lo+1.
+    auto run_steps = [&](int lo, int hi, bool streamed, bool primed, f64x2 (&r0)[JJ], f64x2 (&r1)[JJ], auto&& body) {
+        if (lo >= hi) return;
+        auto fetch = [&](int st, f64x2 (&rowv)[JJ]) {
+            if (streamed) fetch_streamed(st, rowv);
+            else fetch_resident(st, rowv);
+        };
+        if (!primed) {
+            fetch(lo, r0);
+            fetch(min(lo + 1, hi - 1), r1);
         }
+        for (int st = lo;; st += 2) {
+            body(st, r0);
+            const bool more = st + 2 < hi;
+            if (more) fetch(st + 2, r0);
+            if (st + 1 < hi) body(st + 1, r1);
+            if (!more) break;
+            fetch(min(st + 3, hi - 1), r1);
+        }
+    };
+    // four lanes per word finish a normaliser from the transpose area
+    auto finish_sum = [&]() {
+        double2 s2 = mysrc[0];
+#pragma unroll
+        for (int x = 1; x < 4; ++x) {
+            const double2 v2 = mysrc[4 * x];
+            s2.x += v2.x;
+            s2.y += v2.y;
+        }
+        double s = s2.x + s2.y;
+        s += dpp_f64<0xB1>(s);              // the word's other lane of this row
+        return swap16_add(s, s);            // ... and of the group's other row
     };
 
     for (;;) {                                                            // :174
         const int buf = it & 1;
+        f64x2 r0[JJ], r1[JJ];
+        const int nS0 = min(nS, 8);                                       // streamed steps of the first round
+        if (nS0 > 0) {                                                    // requested before the tier R work
+            fetch_streamed(0, r0);
+            fetch_streamed(min(1, nS0 - 1), r1);
+        }
 
         // A(R). tier R partial normalisers -> LDS transpose
 #pragma unroll
@@ -238,60 +298,64 @@ __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, in
             myred[(g * RWL + i) * RS + c] = a0;
         }
         if (moved <= thresh || left <= 0) break;                          // :189 (mean <= tol), :174
-        // the first tail rows are requested before the transposes are read back
-        double2 rowv[JJ], rown[JJ];
-        double cntc = 0.0, cntn = 0.0;
-        if (NTW > 0) load_rows(0, rowv, cntc);
         wave_lds_exchange();
         {
-            double2 s2 = mysrc[0];
-#pragma unroll
-            for (int x = 1; x < 4; ++x) {
-                const double2 v2 = mysrc[4 * x];
-                s2.x += v2.x;
-                s2.y += v2.y;
-            }
-            double s = s2.x + s2.y;
-            s += dpp_f64<0xB1>(s);          // the word's other lane of this row
-            s = swap16_add(s, s);           // ... and of the group's other row
+            const double s = finish_sum();
             nrm_mine = s;
             if (word_live && !(s > 1e-280 && s < 1e300)) bad = 1;
             r_mine = word_live ? my_cnt * rcp_newton(s) : 0.0;
         }
 
-        // B(R). q[k] over tier R
         double q[KRL];
-        row_bcast_matvec<RWL, 2>(q, r_mine, B);
-
-        // tail words, two per step, fused; the next step's rows are in flight while this one is used
-        for (int off = 0; off < NTW; off += 2) {
-            if (off + 2 < NTW) load_rows(off + 2, rown, cntn);
-            double a0 = rowv[0].x * tq[0];
-            a0 = fma(rowv[0].y, tq[1], a0);
+        for (int st0 = 0; st0 == 0 || (MULTI && st0 < nsteps); st0 += 8) {
+            const int stn = min(st0 + 8, nsteps);
+            const int sS = min(st0, nS), eS = min(stn, nS);               // the round's streamed steps [sS, eS)
+            const int sL = max(st0, nS), eL = stn;                        // ... and LDS steps [sL, eL)
+            // ---- pass 1 (the transposes of the previous finish have been read by this wavefront) ----
+            wave_lds_exchange();
+            auto dot_to_transpose = [&](int st, const f64x2 (&rowv)[JJ]) {
+                double a0 = rowv[0].x * tq[0], a1 = rowv[0].y * tq[1];
 #pragma unroll
-            for (int jj = 1; jj < JJ; ++jj) {
-                a0 = fma(rowv[jj].x, tq[2 * jj], a0);
-                a0 = fma(rowv[jj].y, tq[2 * jj + 1], a0);
+                for (int jj = 1; jj < JJ; ++jj) {
+                    a0 = fma(rowv[jj].x, tq[2 * jj], a0);
+                    a1 = fma(rowv[jj].y, tq[2 * jj + 1], a1);
+                }
+                myred[(g * RWL + (st - st0)) * RS + c] = a0 + a1;
+            };
+            run_steps(sS, eS, true, st0 == 0, r0, r1, dot_to_transpose);
+            run_steps(sL, eL, false, false, r0, r1, dot_to_transpose);
+            // the first rows of pass 2 are requested before the normalisers are finished
+            const bool s_first = sS < eS;
+            if (s_first) {
+                fetch_streamed(sS, r0);
+                fetch_streamed(min(sS + 1, eS - 1), r1);
             }
-            const double sn = group32_sum(a0);
-            const int i = off + g;
-            const bool live = i < nmineT;
-            if (live && !(sn > 1e-280 && sn < 1e300)) bad = 1;
-            const double rn = live ? cntc * rcp_newton(sn) : 0.0;
-            if (c == 0) {
-                mynrmT[i] = sn;
-                myrrT[i] = rn;
+            wave_lds_exchange();
+            if (st0 < stn) {
+                const int st = st0 + my_slot;                 // the step whose word (of group g) this lane finishes
+                const int i = tail_index(min(st, nsteps - 1));
+                const bool live = st < stn && i < nmineT;
+                const double sn = finish_sum();
+                if (live && !(sn > 1e-280 && sn < 1e300)) bad = 1;
+                const double rn = live ? mycntT[i] * rcp_newton(sn) : 0.0;
+                if (my_part == 0 && st < stn) {
+                    mynrmT[i] = sn;
+                    myrrT[i] = rn;
+                }
             }
+            // ---- B(R) once, then pass 2: topic sums of the round's words ----
+            if (st0 == 0) row_bcast_matvec<RWL, 2>(q, r_mine, B);
+            wave_lds_exchange();                              // r of the round's words is in LDS
+            auto accumulate = [&](int st, const f64x2 (&rowv)[JJ]) {
+                const double rn = myrrT[tail_index(st)];
 #pragma unroll
-            for (int jj = 0; jj < JJ; ++jj) {
-                q[2 * jj] = fma(rn, rowv[jj].x, q[2 * jj]);
-                q[2 * jj + 1] = fma(rn, rowv[jj].y, q[2 * jj + 1]);
-            }
-            if (off + 2 < NTW) {
-#pragma unroll
-                for (int jj = 0; jj < JJ; ++jj) rowv[jj] = rown[jj];
-                cntc = cntn;
-            }
+                for (int jj = 0; jj < JJ; ++jj) {
+                    q[2 * jj] = fma(rn, rowv[jj].x, q[2 * jj]);
+                    q[2 * jj + 1] = fma(rn, rowv[jj].y, q[2 * jj + 1]);
+                }
+            };
+            run_steps(sS, eS, true, s_first, r0, r1, accumulate);
+            run_steps(sL, eL, false, false, r0, r1, accumulate);
         }
 
         // the two word groups (one permlane32 swap level); lane (g, c) keeps registers j = m + g*JJ
@@ -310,20 +374,21 @@ __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, in
 #pragma unroll
             for (int w = 0; w < W; ++w) part[w] = red[(size_t)w * (L::red_wave / 8) + tid];
             keep_together(part);
+            const double t_mine = tt[buf * KT + tid], a_k = alphaS[tid];
             double s0 = part[0], s1 = part[1];
 #pragma unroll
             for (int w = 2; w < W; w += 2) {
                 s0 += part[w];
                 s1 += part[w + 1];
             }
-            const double gnew = fma(t_mine, s0 + s1, alpha_k);            // :185
+            const double gnew = fma(t_mine, s0 + s1, a_k);                // :185
             const double diff = fabs(gnew - gam);                         // :187
-            gam_prev = gam;
+            gprevS[tid] = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
-            t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;   // (no resident coefficients: the
-                                                                             //  registers go to the row prefetch)
-            tt[(buf ^ 1) * KT + tid] = t_mine;
+            ExpDigammaScalarCoef coef;                                    // scalar registers, fetched here: no
+            coef.load();                                                  // vector registers to spare in this kernel
+            tt[(buf ^ 1) * KT + tid] = topic_live ? exp_digamma_minus_with(gam, psi_total, coef) : 0.0;
             if (tid == 0) chg[buf ^ 1] = 0ull;
         }
         ++it;
@@ -373,7 +438,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, in
         row_bcast_all<RWL, 2>(r_mine, rl);
 #pragma unroll
         for (int i = 0; i < RWL; ++i)
-            if (wid[i] >= 0) term1 = fma(rl[i], g_row_dot(wid[i]), term1);
+            if (wbR + i < N) term1 = fma(rl[i], g_row_dot(p.term_id[lo + wbR + i]), term1);
         for (int off = 0; off < NTW; off += 2) {
             const int i = off + g;
             term1 = fma(myrrT[i], g_row_dot(myidsT[i]), term1);      // dead slots: r = 0, id 0
@@ -392,8 +457,8 @@ __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, in
     double term2 = 0.0, lse_term = 0.0, lgam = 0.0, gsum = 0.0;
     if (topic_live) {
         const double t_last = tt[last * KT + tid];
-        const double moved_k = gam - alpha_k;
-        const double ltv = digamma(gam_prev) - psi_total;
+        const double moved_k = gam - alphaS[tid];
+        const double ltv = digamma(gprevS[tid]) - psi_total;
         term2 = ltv * moved_k;
         if (p.heldout) lse_term = p.topic_lse[tid] * moved_k;
         lgam = lgamma_pos(gam);

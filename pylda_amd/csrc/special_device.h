@@ -185,6 +185,47 @@ __device__ __forceinline__ double exp_digamma_minus_with(double x, double c, con
     return y * k.exp_of(tail);
 }
 
+// The same coefficients fetched into SCALAR registers from constant memory each time they are
+// used (kernels that have no vector registers to spare: a VOP3 FMA takes one scalar operand, and
+// literals the compiler hoists out of the inner loop would otherwise be spilled to scratch).
+// The opaque pointer keeps the loads where they are written.
+__constant__ double kExpDigammaTable[24] = {
+    9.0, 10.0, 60.0, 1308.0, 12176.0, 40320.0, 5.0, 240.0, 3924.0, 24352.0,
+    1.0 / 12.0, -1.0 / 120.0, 1.0 / 252.0, -1.0 / 240.0, 1.0 / 132.0, -691.0 / 32760.0,
+    1.0 / 24.0, 1.0 / 720.0, 1.0 / 40320.0, 1.0 / 3628800.0, 1.0 / 479001600.0, 0.0, 0.0, 0.0};
+
+struct ExpDigammaScalarCoef {
+    double nine, ten, d3, d2, d1, d0, n4, n3, n2, n1, b1, b2, b3, b4, b5, b6;
+    double a2, a3, a4, a5, a6;
+    __device__ __forceinline__ void load()
+    {
+        typedef const double __attribute__((address_space(4)))* const_table_ptr;
+        const_table_ptr t = (const_table_ptr)kExpDigammaTable;
+        asm volatile("" : "+s"(t));
+        nine = t[0], ten = t[1], d3 = t[2], d2 = t[3], d1 = t[4], d0 = t[5], n4 = t[6], n3 = t[7], n2 = t[8], n1 = t[9];
+        b1 = t[10], b2 = t[11], b3 = t[12], b4 = t[13], b5 = t[14], b6 = t[15];
+        a2 = t[16], a3 = t[17], a4 = t[18], a5 = t[19], a6 = t[20];
+    }
+    // exp_shallow with the two-constant terms taking their addend from the table
+    __device__ __forceinline__ double exp_of(double x) const
+    {
+        const double kf = __builtin_rint(x * 1.4426950408889634074);
+        double r = fma(-kf, 6.93147180369123816490e-01, x);
+        r = fma(-kf, 1.90821492927058770002e-10, r);
+        const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+        const double p0 = r + 1.0;
+        const double p1 = fma(r, 1.0 / 6.0, 0.5);
+        const double p2 = fma(r, 1.0 / 120.0, a2);
+        const double p3 = fma(r, 1.0 / 5040.0, a3);
+        const double p4 = fma(r, 1.0 / 362880.0, a4);
+        const double p5 = fma(r, 1.0 / 39916800.0, a5);
+        const double p6 = fma(r, 1.0 / 6227020800.0, a6);
+        const double q0 = fma(p1, r2, p0), q1 = fma(p3, r2, p2), q2 = fma(p5, r2, p4);
+        const double o0 = fma(q1, r4, q0), o1 = fma(p6, r4, q2);
+        return ldexp(fma(o1, r8, o0), (int)kf);
+    }
+};
+
 struct ExpDigammaLiterals {
     __device__ __forceinline__ double exp_of(double x) const { return exp_shallow(x); }
     static constexpr double nine = 9.0, ten = 10.0;
