@@ -103,6 +103,9 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
     for (int i = 0; i < RN; ++i) r[i] = nrm[i] = 0.0;
     int it = 0;
     int bad = 0;
+    // moved * 2^-40 <= tol * K  <=>  moved <= floor(tol * K * 2^40): an integer compare on the fixed-point sum
+    const double thresh_f = p.tol * K * kChangeScale;
+    const long long thresh = !(thresh_f >= 0.0) ? -1ll : thresh_f >= 9.2e18 ? 0x7fffffffffffffffll : (long long)thresh_f;
     while (it < p.max_iter) {                                             // :174
         const int buf = it & 1;
         // t[k] = exp(psi(gamma_k) - psi(sum gamma))  (the constant cancels in :182)
@@ -164,9 +167,7 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
 #pragma unroll
             for (int m = 0; m < Q; ++m) myred[(tbase + m) * 17 + c] = v[m];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_lds_exchange();
         double s;
         {
             const int g = lane / LP, part = lane % LP;
@@ -174,24 +175,19 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
             s = src[0];
 #pragma unroll
             for (int x = 1; x < 16 / LP; ++x) s += src[x];
-#pragma unroll
-            for (int m = 1; m < LP; m <<= 1) s += __shfl_xor(s, m, kWave);
+            s = lane_group_sum<LP>(s);      // LP (2, 4 or 8) neighbouring lanes share a topic: DPP, no LDS
         }
         // gamma update, this lane group's topic
         const double gnew = fma(tv, s, alpha_k);                          // :185
         // sum_k |gamma' - gamma| as a 2^40 fixed-point LDS atomic: integer addition is associative,
         // so the stop decision is order-independent (and there is no 6-level wavefront reduction
         // on the serial path)
-        if (topic_live && (lane % LP) == 0) {
-            const double clipped = fmin(fabs(gnew - gam), 1024.0) * kChangeScale;   // :187
-            atomicAdd(&chg[buf], (unsigned long long)(clipped + 0.5));
-        }
+        if (topic_live && (lane % LP) == 0) atomicAdd(&chg[buf], change_fixed(fabs(gnew - gam)));   // :187
         gam = gnew;                                                       // :188
         if (tid == 0) chg[buf ^ 1] = 0ull;
         ++it;
         __syncthreads();
-        const double change = (double)chg[buf] * (1.0 / kChangeScale);
-        if (change <= p.tol * K) break;                                   // :189 (mean <= tol)
+        if ((long long)chg[buf] <= thresh) break;                         // :189 (mean <= tol)
     }
 
     bad = __syncthreads_or(bad);
