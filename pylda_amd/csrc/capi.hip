@@ -249,6 +249,9 @@ bool qwide_ok(const pylda_ctx* ctx, int n)
            ctx->lds_limit >= 160 * 1024;
 }
 
+// 1: one round of tail steps per wavefront (at most 8 steps = 16 words: N <= 256), 2: several.
+int qwide_rounds_for(int n) { return n <= kQwRegWords + 8 * 16 ? 1 : 2; }
+
 // Streaming quilt kernel: any ldk that is a multiple of 64 up to 512, documents up to 1000 terms.
 bool qstream_ok(const pylda_ctx* ctx, int n) { return ctx->ldk % 64 == 0 && ctx->ldk <= 512 && n <= 1000; }
 
@@ -321,6 +324,7 @@ void build_plan(pylda_corpus* c)
             if (vj != v) break;
             if (v == kQuilt && quilt_rwl_for(ctx, c->h_terms_sorted[j]) != quilt_rwl_for(ctx, c->h_terms_sorted[i])) break;
             if (v == kColumn && column_rnw_for(ctx, c->h_terms_sorted[j]) != column_rnw_for(ctx, c->h_terms_sorted[i])) break;
+            if (v == kQwide && qwide_rounds_for(c->h_terms_sorted[j]) != qwide_rounds_for(c->h_terms_sorted[i])) break;
             if (v == kSlab) {
                 const SlabGeom gi = slab_geom_for(ctx, c->h_terms_sorted[i]), gj = slab_geom_for(ctx, c->h_terms_sorted[j]);
                 if (gi.RK != gj.RK || gi.RN != gj.RN) break;
@@ -339,7 +343,8 @@ void build_plan(pylda_corpus* c)
         L.lds_bytes = lds_first;
         L.rn = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RN
              : v == kColumn ? column_rnw_for(ctx, c->h_terms_sorted[i])
-             : v == kQuilt ? quilt_rwl_for(ctx, c->h_terms_sorted[i]) : 0;
+             : v == kQuilt ? quilt_rwl_for(ctx, c->h_terms_sorted[i])
+             : v == kQwide ? qwide_rounds_for(c->h_terms_sorted[i]) : 0;
         L.rk = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RK : 0;
         c->plan.push_back(L);
         i = j;
@@ -482,7 +487,7 @@ int launch_qwide(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 
 int launch_qwide_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
-    const bool multi = L.n_cap > kQwRegWords + 8 * 16;     // more than one round of tail steps per wavefront
+    const bool multi = L.rn != 1;       // more than one round of tail steps per wavefront
     switch (ctx->ldk / 64) {
     case 2: return multi ? launch_qwide<2, true>(ctx, p, L) : launch_qwide<2, false>(ctx, p, L);
     case 3: return multi ? launch_qwide<3, true>(ctx, p, L) : launch_qwide<3, false>(ctx, p, L);
