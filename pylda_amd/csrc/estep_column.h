@@ -150,9 +150,7 @@ __global__ __launch_bounds__(kWave* W) void estep_column_kernel(EstepParams p)
 #pragma unroll
             for (int m = 0; m < Q; ++m) myred[(wbase + m) * 17 + c] = v[m];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_lds_exchange();
         {
             const int part = lane % LPW;
             const double* src = myred + (lane / LPW) * 17 + part * (16 / LPW);
@@ -166,9 +164,7 @@ __global__ __launch_bounds__(kWave* W) void estep_column_kernel(EstepParams p)
             r_mine = word_live ? my_cnt * rcp_newton(s) : 0.0;
             if (part == 0) rr[wave * RNW + lane / LPW] = r_mine;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_lds_exchange();
 
         // B. q[k] over this wavefront's words (r broadcast from LDS, two words per read)
         double q0[KR], q1[KR];
@@ -197,8 +193,7 @@ __global__ __launch_bounds__(kWave* W) void estep_column_kernel(EstepParams p)
             const double diff = topic_live ? fabs(gnew - gam) : 0.0;      // :187
             gam_prev = gam;
             gam = gnew;                                                   // :188
-            const double clipped = fmin(diff, 1024.0) * kChangeScale;
-            atomicAdd(&chg[buf], (unsigned long long)(clipped + 0.5));
+            atomicAdd(&chg[buf], change_fixed(diff));
             t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
             tt[(buf ^ 1) * KT + tid] = t_mine;
             if (tid == 0) chg[buf ^ 1] = 0ull;

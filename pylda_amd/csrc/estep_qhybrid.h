@@ -132,9 +132,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
     }
     for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
     local = wave_sum(local);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wave_lds_exchange();
     for (int off = 0; off < NLW; off += 4) {
         const int i = off + g;
         if (i >= NLW) continue;
@@ -198,9 +196,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
             }
             myred[(g * RWL + i) * 17 + c] = a0 + a1;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_lds_exchange();
         {
             const int part = lane % LPW;
             const double* src = myred + (lane / LPW) * 17 + part * PER;
@@ -218,9 +214,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
             r_mine = word_live ? my_cnt * rcp_newton(s) : 0.0;
             if (part == 0) myrr[lane / LPW] = r_mine;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_lds_exchange();
 
         // B. q[k] over tier R (registers), then the tail rows
         double q[KRL];
@@ -252,9 +246,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
                 a1 = fma(rowv[jj].y, t2.y, a1);
             }
             myred[g * 17 + c] = a0 + a1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            wave_lds_exchange();
             const double* src = myred + g * 17;              // the 16 partials of this lane group's word
             double s0 = src[0], s1 = src[1], s2 = src[2], s3 = src[3];
 #pragma unroll
@@ -302,8 +294,7 @@ __global__ __launch_bounds__(kWave* W) void estep_qhybrid_kernel(EstepParams p, 
             const double diff = topic_live ? fabs(gnew - gam) : 0.0;      // :187
             gam_prev = gam;
             gam = gnew;                                                   // :188
-            const double clipped = fmin(diff, 512.0) * kChangeScale;
-            atomicAdd(&chg[buf], (unsigned long long)(clipped + 0.5));
+            atomicAdd(&chg[buf], change_fixed(diff));
             t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
             tt[(buf ^ 1) * KT + tid] = t_mine;
             if (tid == 0) chg[buf ^ 1] = 0ull;

@@ -140,9 +140,7 @@ __global__ __launch_bounds__(kWave* W, (KRL <= 16 ? 4 : 2)) void estep_qstream_k
                 }
                 myred[(off + g) * 17 + c] = i < nmine ? a0 + a1 : 0.0;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            wave_lds_exchange();
             if (lane < span) {
                 const double* src = myred + lane * 17;
                 double s0 = src[0], s1 = src[1];
@@ -159,9 +157,7 @@ __global__ __launch_bounds__(kWave* W, (KRL <= 16 ? 4 : 2)) void estep_qstream_k
                 mynrm[i] = s;
                 myrr[i] = live ? cnt * rcp_newton(s) : 0.0;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            wave_lds_exchange();
         }
         // B. q[k] = sum over this lane's words (rows re-read), then over the 4 slots
         double q[KRL];
@@ -201,8 +197,7 @@ __global__ __launch_bounds__(kWave* W, (KRL <= 16 ? 4 : 2)) void estep_qstream_k
             const double diff = topic_live ? fabs(gnew - gam) : 0.0;      // :187
             gam_prev = gam;
             gam = gnew;                                                   // :188
-            const double clipped = fmin(diff, 256.0) * kChangeScale;
-            atomicAdd(&chg[buf], (unsigned long long)(clipped + 0.5));
+            atomicAdd(&chg[buf], change_fixed(diff));
             t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
             tt[(buf ^ 1) * KT + tid] = t_mine;
             if (tid == 0) chg[buf ^ 1] = 0ull;
