@@ -285,6 +285,25 @@ def test_nips_k500_matches_reference_goldens(capi):
     check_against(held, g["heldout_gamma"], g["heldout_words_ll"], g["heldout_iters"], ll_key="doc_words_ll")
 
 
+@pytest.mark.parametrize("K,V,mean_len", [(100, 900, 150), (128, 1200, 210), (256, 3000, 190), (256, 3000, 330)])
+def test_iteration_cap_and_threshold_on_register_kernels(capi, K, V, mean_len):
+    """The register-resident kernels evaluate the stop test of iteration i behind the first half of
+    iteration i+1 (an integer compare on a fixed-point sum): caps, loose / zero / negative thresholds
+    must give the reference's iteration counts (variational_bayes.py:174,187-190)."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(K + mean_len)
+    ptr, ids, cts = random_corpus(rng, 24, V, mean_len)
+    eta = rng.gamma(100.0, 0.01, (K, V))
+    alpha = rng.uniform(0.05, 1.0, K)
+    for mi, tol in [(1, 1e-6), (2, 1e-6), (50, 1e-1), (7, 0.0), (5, -1.0), (50, 1e-3)]:
+        ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
+        out = run(capi, alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
+        assert np.array_equal(out["iters"], ref["iters"]), (mi, tol)
+        assert rel_err(out["gamma"], ref["gamma"]) < 1e-9
+        assert np.max(np.abs(out["doc_ll"] - ref["doc_ll"]) / (np.abs(ref["doc_ll"]) + 1.0)) < 1e-9
+        assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+
+
 def test_edge_cases_empty_ragged_and_limits(capi):
     from oracle import c_oracle
     rng = np.random.default_rng(0)
