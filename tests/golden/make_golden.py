@@ -237,7 +237,7 @@ def make_nips(vb):
           % (len(ptr) - 1, np.diff(ptr).max(), ll, iters.mean()))
 
 
-def make_nips_trace(vb, iterations):
+def make_nips_trace(vb, iterations, out=None):
     """BASELINE.json cfg 5: parsed/nips.88-05, K=500, train = first 2,235 documents, test = last 248
     (SURVEY 8d), seed 0, `iterations` learning() calls of the reference (about 5 minutes each on one
     core), then inference() on the test split.  The trace is rewritten after every iteration so that
@@ -257,7 +257,7 @@ def make_nips_trace(vb, iterations):
     parsed_test = quiet(m.parse_data, test)
     tptr, ttid, ttct = csr_of(parsed_test)
     joint, alphas, heldout = [], [], []
-    out = os.path.join(HERE, "nips_trace_k500.npz")
+    out = out or os.path.join(HERE, "nips_trace_k500.npz")
     for it in range(iterations):
         joint.append(quiet(m.learning))
         alphas.append(m._alpha_alpha.copy())
@@ -290,6 +290,7 @@ if __name__ == "__main__":
     ap.add_argument("--trace", type=int, default=3, help="AP K=10 trace length (iterations)")
     ap.add_argument("--only", default="", help="comma list of: tiny,ap,special,nips,nipstrace")
     ap.add_argument("--nips-iterations", type=int, default=50)
+    ap.add_argument("--nips-trace-out", default=None, help="write the nips trace here instead of over the committed fixture")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
     _, vb = load_reference()
@@ -302,4 +303,4 @@ if __name__ == "__main__":
     if not only or "nips" in only:
         make_nips(vb)
     if "nipstrace" in only:                 # hours of CPU: only on request
-        make_nips_trace(vb, args.nips_iterations)
+        make_nips_trace(vb, args.nips_iterations, args.nips_trace_out)
