@@ -156,7 +156,11 @@ int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, int64_t* estep_call
  *                    second table gather per document; doc_ll[] is then unavailable;
  *   "force_logspace" 0|1  run every document through the log-space
  *                         safety-net kernel (the reference's formulation);
- *   "force_variant"  -1 (automatic) or a kernel variant index. */
+ *   "force_variant"  -1 (automatic) or a kernel variant index 0..9 (generic LDS 64/256/512
+ *                    threads, generic global, slab, column, quilt, streaming, hybrid, wide tiered);
+ *                    a variant that cannot take a document falls back to the automatic choice;
+ *   "quilt_odd", "quilt12", "column_waves", "gather_rows"  A/B switches of kernel geometry
+ *                    ("Tried and measured"). */
 int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value);
 
 /* Test hook: evaluate the device special functions on n host values. */
