@@ -42,10 +42,29 @@ struct EstepParams {
     int tile_stride;          // LDS row stride in doubles (odd)
 };
 
+// Sum over the 64 lanes, result in every lane, without the LDS crossbar (ds_bpermute costs an LDS
+// round trip per level): four DPP levels inside each 16-lane row, then one permlane16 and one
+// permlane32 swap level across the rows.  Fixed order, so results are run-to-run identical.
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int m = kWave / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+#define PYLDA_DPP_ADD(CTRL)                                                                     \
+    v += __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false),   \
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false))
+    PYLDA_DPP_ADD(0xB1);        // quad_perm [1,0,3,2]
+    PYLDA_DPP_ADD(0x4E);        // quad_perm [2,3,0,1]
+    PYLDA_DPP_ADD(0x141);       // row_half_mirror
+    PYLDA_DPP_ADD(0x140);       // row_mirror
+#undef PYLDA_DPP_ADD
+    {
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);       // rows 0+1 | 0+1 | 2+3 | 2+3
+    }
+    {
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);       // both halves
+    }
     return v;
 }
 
