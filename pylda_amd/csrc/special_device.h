@@ -11,10 +11,21 @@
 
 namespace pylda {
 
+// 1/x for normal positive x: v_rcp_f64 seed + two Newton steps (the refinement the
+// compiler's IEEE division uses, without its scaling fix-ups).
+__device__ __forceinline__ double rcp_newton(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
 // Asymptotic psi(x), valid to < 1e-16 absolute for x >= 10.
 __device__ __forceinline__ double digamma_asymptotic(double x)
 {
-    const double inv = 1.0 / x;
+    const double inv = rcp_newton(x);
     const double w = inv * inv;
     // sum_{n>=1} B_2n / (2n x^2n)
     double s = 1.0 / 12.0;                       // highest kept term: x^-14
@@ -48,19 +59,8 @@ __device__ __forceinline__ double digamma(double x)
     const double n1234 = fma(n12, d34, n34 * d12), d1234 = d12 * d34;
     // + 1/q0
     const double num = fma(n1234, q0, d1234), den = d1234 * q0;
-    const double shift = (2.0 * x + 9.0) * (num / den);
+    const double shift = (2.0 * x + 9.0) * (num * rcp_newton(den));
     return digamma_asymptotic(x + 10.0) - shift;
-}
-
-// 1/x for normal positive x: v_rcp_f64 seed + two Newton steps (the refinement the
-// compiler's IEEE division uses, without its scaling fix-ups).
-__device__ __forceinline__ double rcp_newton(double x)
-{
-    double y = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-x, y, 1.0);
-    return fma(y, e, y);
 }
 
 // exp(x) for |x| < 700, Estrin-evaluated degree-13 Taylor polynomial on the
@@ -244,7 +244,7 @@ __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 // the recurrence lnG(x) = lnG(x+m) - ln(x (x+1) ... (x+m-1)).
 __device__ __forceinline__ double lgamma_stirling(double x)
 {
-    const double inv = 1.0 / x;
+    const double inv = rcp_newton(x);
     const double w = inv * inv;
     // sum_{n>=1} B_2n / (2n (2n-1) x^(2n-1))
     double s = 43867.0 / 244188.0;               // x^-17
