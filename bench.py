@@ -1,28 +1,39 @@
 #!/usr/bin/env python3
 """bench.py - documents/sec per VB iteration of the MI355X E-step path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload synth100k|synth1m|ap]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload synth100k|synth1m|ap|nips]
 
 A "step" is one outer VB iteration over the rank's resident corpus: the hot
-path (device compute_dirichlet_expectation + per-document phi/gamma kernel +
+path (device compute_dirichlet_expectation + per-document phi/gamma kernels +
 sufficient-statistics accumulation, variational_bayes.py:132-216), the RCCL
 all-reduce of the K*V sufficient statistics when N > 1, and the device M-step /
 alpha update that make the next iteration start from a new model (nothing is
 cached between steps).  Inputs are resident in HBM before the timed region.
+`python bench.py --gpus N` (N > 1) launches its own ranks through
+torch.distributed.run; under an existing launcher (RANK/WORLD_SIZE set) it is a rank.
 
 Workloads (BASELINE.json configs):
   synth100k  cfg 3: synthetic LDA corpus, 100,000 docs PER GPU, V=50k, K=128,
-             mean 200 tokens/doc - weak scaling (default; the single-GPU
-             roofline configuration)
+             mean 200 tokens/doc - weak scaling (default primary line; the
+             single-GPU roofline configuration)
   synth1m    cfg 4: 1,000,000 docs TOTAL, V=100k, K=256, sharded over N GPUs -
              strong scaling
   ap         cfg 2: associated-press train split (committed parsed fixture),
              K=10, replicated per GPU (latency-bound, 2000 documents)
+  nips       cfg 5: parsed/nips.88-05 (committed parsed fixture), K=500,
+             train = first 2,235 documents
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-`roofline` (HBM bound, algorithmic bytes B = nnz*(8+16K) + D*(8K+8) per launch,
-SURVEY 8d) and `cpu_baseline` (the numpy restatement of the reference timed on
-this host, single thread, bounded sample).
+The default run prints ONE JSON line on rank 0: the primary record (cfg 3) with
+`roofline` and `cpu_baseline`, and as sub-records the other configurations timed
+the same way in the same process: `synth1m` (cfg 4, every N), and at N = 1 also
+`ap_k10` (cfg 2) and `nips_k500` (cfg 5, with the held-out per-token
+log-likelihood after 50 iterations against the reference's own value).
+
+roofline: HBM bound, algorithmic bytes B = nnz*(8+16K) + D*(8K+8) per E-step
+ over the kernels that move them - the document kernels of the E-step
+(one launch class per words-per-lane instantiation, run concurrently) PLUS the
+sufficient-statistics pass (gather + finalize) - timed with HIP events on the
+launch streams inside the timed region.
 """
 import argparse
 import json
@@ -40,37 +51,53 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec)
 CHUNK = 25000
 
+# (documents, nnz, sum of term ids, sum of counts) of the generated corpora: numpy PCG64 draws
+# (pylda_amd/corpus.py::synthetic_lda_shard), independent of torch version and device.
+EXPECTED_CHECKSUM = {
+    "synth100k": [100000, 19651258, 493018266666, 19997266],       # one GPU's 100k documents (N = 1)
+    "synth1m": [1000000, 198210795, 9901022603303, 199984652],
+}
+
 
 def algorithmic_bytes(nnz, D, K):
     return nnz * (8 + 16 * K) + D * (8 * K + 8)
 
 
 def build_workload(name, rank, world, device, docs_override=None):
-    from pylda_amd.corpus import synthetic_lda_corpus_torch
+    from pylda_amd.corpus import synthetic_lda_shard
+    workers = max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
     if name == "synth100k":
         per_gpu = docs_override or 100000
         V, K, seed = 50000, 128, 1234
-        chunks = (per_gpu + CHUNK - 1) // CHUNK
-        ptr, ids, cts = synthetic_lda_corpus_torch(per_gpu * world, V, 128, 200, seed, device=device,
-                                                   chunk=CHUNK, first_chunk=rank * chunks,
-                                                   shard_chunks=chunks)
-        return dict(ptr=ptr, ids=ids, cts=cts, V=V, K=K, scaling="weak",
+        total = per_gpu * world
+        ptr, ids, cts = synthetic_lda_shard(total, V, rank * per_gpu, (rank + 1) * per_gpu, 128, 200, seed,
+                                            chunk=min(CHUNK, per_gpu), device=device, workers=workers)
+        return dict(ptr=ptr, ids=ids, cts=cts, V=V, K=K, scaling="weak", cfg="cfg3",
                     label="synthetic LDA corpus cfg3: %d docs/GPU, V=50000, K=128, mean 200 tokens/doc" % per_gpu)
     if name == "synth1m":
         total = docs_override or 1000000
         V, K, seed = 100000, 256, 5678
-        n_chunks = (total + CHUNK - 1) // CHUNK
-        per = (n_chunks + world - 1) // world
-        ptr, ids, cts = synthetic_lda_corpus_torch(total, V, 128, 200, seed, device=device, chunk=CHUNK,
-                                                   first_chunk=rank * per, shard_chunks=per)
-        return dict(ptr=ptr, ids=ids, cts=cts, V=V, K=K, scaling="strong",
-                    label="synthetic LDA corpus cfg4: %d docs total, V=100000, K=256, sharded" % total)
+        chunk = min(CHUNK, max(1, total // max(1, world)))
+        n_chunks = (total + chunk - 1) // chunk
+        # contiguous runs of whole chunks per rank: every chunk holds `chunk` documents of the same
+        # distribution, so the ranks' nnz differ by well under 1 % (reported as nnz_imbalance)
+        first = (n_chunks * rank) // world
+        last = (n_chunks * (rank + 1)) // world
+        ptr, ids, cts = synthetic_lda_shard(total, V, first * chunk, min(total, last * chunk), 128, 200, seed,
+                                            chunk=chunk, device=device, workers=workers)
+        return dict(ptr=ptr, ids=ids, cts=cts, V=V, K=K, scaling="strong", cfg="cfg4",
+                    label="synthetic LDA corpus cfg4: %d docs total, V=100000, K=256, sharded by document" % total)
     if name == "ap":
         g = np.load(os.path.join(ROOT, "tests", "golden", "ap_train_k10.npz"))
         return dict(ptr=g["doc_ptr"].astype(np.int64), ids=g["term_id"].astype(np.int32),
                     cts=g["term_ct"].astype(np.int32), V=int(g["eta"].shape[1]), K=10,
-                    scaling="weak", eta=g["eta"], alpha=g["alpha"],
+                    scaling="weak", eta=g["eta"], alpha=g["alpha"], cfg="cfg2",
                     label="associated-press train split (2000 docs, V=6806), K=10, replicated per GPU")
+    if name == "nips":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "nips_trace_k500.npz"))
+        return dict(ptr=g["doc_ptr"].astype(np.int64), ids=g["term_id"].astype(np.int32),
+                    cts=g["term_ct"].astype(np.int32), V=len(g["words"]), K=int(g["K"]), scaling="weak", cfg="cfg5",
+                    label="parsed/nips.88-05 train split (2235 docs, V=3209), K=500, replicated per GPU")
     raise SystemExit("unknown workload %r" % name)
 
 
@@ -102,42 +129,56 @@ def c_oracle_rate(alpha, eta, ptr, ids, cts, n):
     return n / (time.perf_counter() - t0)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="synth100k", choices=["synth100k", "synth1m", "ap"])
-    ap.add_argument("--docs", type=int, default=None, help="override the corpus size (smoke runs)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ap-extra", action="store_true")
-    ap.add_argument("--variant", type=int, default=-1, help="force a kernel variant (A/B runs)")
-    ap.add_argument("--option", action="append", default=[], help="name=value library option (A/B runs)")
-    args = ap.parse_args()
+class Job(object):
+    """Process-wide state of one bench run: rank, device, process group."""
 
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    group = None
-    if world > 1:
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        self.group = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.share_gpu:      # test mode: every rank on GPU 0 (RCCL refuses that), exchange over gloo
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+            self.group = dist.group.WORLD
+
+    def barrier(self):
+        if self.group is not None:
+            import torch.distributed as dist
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, values, op="sum"):
+        """all-reduce a short list of floats over the ranks (identity at N = 1)."""
+        if self.group is None:
+            return list(values)
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        group = dist.group.WORLD
+        backend_dev = self.device if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=backend_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        return [float(x) for x in t.cpu()]
 
-    from pylda_amd import _capi, distributed
+
+def measure(job, args, name, steps, warmup, docs=None):
+    """Build the workload, run `warmup` + `steps` learning() iterations, return the record pieces."""
+    from pylda_amd import distributed
+    from pylda_amd.corpus import corpus_checksum
     from pylda_amd.variational_bayes import VariationalBayes
-
-    wl = build_workload(args.workload, rank, world, device, args.docs)
+    t_gen = time.perf_counter()
+    wl = build_workload(name, job.rank, job.world, job.device, docs)
+    t_gen = time.perf_counter() - t_gen
     ptr, ids, cts, V, K = wl["ptr"], wl["ids"], wl["cts"], wl["V"], wl["K"]
     D_local, nnz_local, tokens_local = len(ptr) - 1, int(ptr[-1]), int(cts.sum())
 
@@ -145,121 +186,225 @@ def main():
     eta0 = wl.get("eta")
     if eta0 is None:
         eta0 = np.random.gamma(100., 1. / 100., (K, V))          # variational_bayes.py:95
-    vb = VariationalBayes(hyper_parameter_optimize_interval=1, device=local_rank, process_group=group)
+    vb = VariationalBayes(hyper_parameter_optimize_interval=1, device=job.local_rank, process_group=job.group)
     vb._verbose = False
-    vb._initialize_parsed(ptr, ids, cts, V, K, 1.0 / K, 1.0 / V, eta=eta0)
+    t_init = time.perf_counter()
+    vb._initialize_parsed(ptr, ids, cts, V, K, 1.0 / K, 1.0 / V, eta=eta0)      # upload + launch schedule
+    t_init = time.perf_counter() - t_init
     if "alpha" in wl:
         vb._alpha_alpha = wl["alpha"].copy()
     ctx = vb._context()
     if args.variant >= 0:
         ctx.set_option("force_variant", args.variant)
     for kv in args.option:
-        name, value = kv.split("=")
-        ctx.set_option(name, int(value))
-    if group is None:
+        oname, value = kv.split("=")
+        ctx.set_option(oname, int(value))
+    if job.group is None:
         distributed.bind_to_torch_stream(ctx)
 
-    def barrier():
-        if group is not None:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    t_first = time.perf_counter()
+    first_steps = max(1, warmup)
+    for _ in range(first_steps):
         vb.learning()
+    job.torch.cuda.synchronize()
+    t_first = time.perf_counter() - t_first      # includes the one-off postings (CSC) build of the first E-step
     ctx.set_profiling(True)
     ctx.kernel_time()
-    barrier()
+    vb._train_corpus.plan()
+    job.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         joint = vb.learning()
-    barrier()
+    job.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, kernel_calls = ctx.kernel_time()
+    doc_ms, ss_ms, calls = ctx.kernel_time()
+    classes = vb._train_corpus.plan()
     ctx.set_profiling(False)
 
-    totals = torch.tensor([elapsed, float(D_local), float(nnz_local)], dtype=torch.float64, device=device)
-    if group is not None:
-        import torch.distributed as dist
-        tmax = totals.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-    D_total, nnz_total = int(totals[1]), int(totals[2])
+    elapsed = job.reduce([elapsed], "max")[0]
+    sums = job.reduce([float(D_local), float(nnz_local)] + [float(x) for x in corpus_checksum(ptr, ids, cts)])
+    nnz_max = job.reduce([float(nnz_local)], "max")[0]
+    D_total, nnz_total = int(sums[0]), int(sums[1])
+    calls = max(1, calls)
+    doc_ms, ss_ms = doc_ms / calls, ss_ms / calls
+    for c in classes:
+        c["kernel_ms"] = c["kernel_ms"] / calls
+    B = algorithmic_bytes(nnz_local, D_local, K)
+    kernel_ms = doc_ms + ss_ms
+    achieved = B / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % name)
+    if os.path.exists(tpath) and docs is None:
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/traffic_%s.json (rocprofv3 --pmc passes of this workload, corrected per " \
+                             "MI355X_MICROARCH.md; not re-measured in this run)" % name
+        except Exception:
+            traffic = None
+    rec = {
+        "value": D_total * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "scaling": wl["scaling"],
+        "config": {"workload": wl["label"], "docs_total": D_total, "nnz_total": nnz_total,
+                   "docs_per_gpu": D_local, "nnz_per_gpu": nnz_local, "tokens_per_gpu": tokens_local,
+                   "nnz_imbalance": nnz_max * job.world / max(1, nnz_total) - 1.0,
+                   "K": K, "V": V, "inner_iterations_cap": 50, "parallelism": "dp%d" % job.world,
+                   "step": "e_step + sstats all-reduce + device m_step + alpha update",
+                   "corpus_checksum": [int(x) for x in sums[2:]]},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": "E-step document kernels (concurrent launch classes) + sufficient-statistics pass "
+                               "(gather + finalize), rank 0, HIP events on the launch streams",
+                     "kernel_ms": kernel_ms, "kernel_ms_documents": doc_ms, "kernel_ms_sstats": ss_ms,
+                     "algorithmic_bytes": B, "launch_classes": classes},
+        "joint_log_likelihood": joint,
+        "startup": {"generate_corpus_s": t_gen, "upload_and_schedule_s": t_init,
+                    "first_%d_steps_s" % first_steps: t_first,
+                    "note": "the first E-step also builds the corpus' postings (CSC) for the statistics gather"},
+    }
+    expected = EXPECTED_CHECKSUM.get(name)
+    if expected is not None and docs is None and (name == "synth1m" or job.world == 1):
+        assert rec["config"]["corpus_checksum"] == expected, \
+            "generated corpus differs from the recorded one: %r vs %r" % (rec["config"]["corpus_checksum"], expected)
+    return rec, vb, ctx, wl
 
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = D_total * args.steps / elapsed
-        kernel_avg_ms = kernel_ms / max(1, kernel_calls)
-        B = algorithmic_bytes(nnz_local, D_local, K)
-        achieved = B / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+
+def fp64_companion(ctx, vb, ptr, K, kernel_ms_documents):
+    """The honest companion: the document kernels are fp64-VALU / latency bound, not HBM bound.
+    flops of the inner loops actually executed = sum_d I_d * 4 * N_d * K (two mat-vecs per iteration)."""
+    _, _, iters = ctx.get_doc_values(vb._train_corpus, want_ll=False)
+    work = float(np.dot(iters.astype(np.float64), np.diff(ptr).astype(np.float64))) * 4.0 * K
+    tflops = work / (kernel_ms_documents * 1e-3) / 1e12 if kernel_ms_documents > 0 else 0.0
+    return {"bound": "fp64 vector FMA", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+            "flops_per_launch": work, "mean_inner_iterations": float(iters.mean())}
+
+
+def cpu_leg(ctx, vb, wl, args, budget_s, max_docs, value):
+    """CPU baseline + per-document log-likelihood delta on a bounded sample (rank 0, N = 1)."""
+    ptr, ids, cts = wl["ptr"], wl["ids"], wl["cts"]
+    alpha = vb._alpha_alpha.copy()
+    eta = vb._eta.copy()
+    rate, n, cpu_ll = cpu_baseline(alpha, eta, ptr, ids, cts, budget_s, max_docs)
+    sample = ctx.corpus(ptr[:n + 1], ids[:ptr[n]], cts[:ptr[n]])
+    gpu = ctx.estep_host(sample, alpha, eta)
+    ctx.set_option("doc_values", 0)
+    sample.close()
+    delta = np.abs(gpu["doc_ll"] - cpu_ll) / np.abs(cpu_ll)
+    return {
+        "cpu_baseline": {
+            "value": rate, "unit": "docs/s", "cores": 1, "kind": "port",
+            "sample": "first %d documents of rank 0's corpus, numpy/scipy restatement of "
+                      "variational_bayes.py:132-216 (oracle/vb_numpy.py), single thread; "
+                      "host has %d cores" % (n, os.cpu_count()),
+            "c_port_docs_per_s": c_oracle_rate(alpha, eta, ptr, ids, cts, n)},
+        "ll_delta": {"max_rel": float(delta.max()), "median_rel": float(np.median(delta)),
+                     "docs": int(n), "bar": 1e-5},
+        "speedup_vs_cpu": value / rate,
+    }
+
+
+def release(vb):
+    if vb._train_corpus is not None:
+        vb._train_corpus.close()
+        vb._train_corpus = None
+    if vb._ctx is not None:
+        vb._ctx.close()
+        vb._ctx = None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="synth100k", choices=["synth100k", "synth1m", "ap", "nips"])
+    ap.add_argument("--docs", type=int, default=None, help="override the corpus size (smoke runs)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", "--no-ap-extra", dest="no_extras", action="store_true",
+                    help="primary record only (no cfg 2 / cfg 4 / cfg 5 sub-records)")
+    ap.add_argument("--extra-docs", type=int, default=None, help="corpus size of the cfg 4 sub-record (smoke runs)")
+    ap.add_argument("--variant", type=int, default=-1, help="force a kernel variant (A/B runs)")
+    ap.add_argument("--option", action="append", default=[], help="name=value library option (A/B runs)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test mode: all ranks on GPU 0, exchange over gloo (exercises the N > 1 path on a 1-GPU box)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # invoked as plain `python bench.py --gpus N`: become the launcher, one rank per GPU
+        os.execv(sys.executable, launcher_argv(args.gpus, sys.argv[1:]))
+
+    job = Job(args)
+    rec, vb, ctx, wl = measure(job, args, args.workload, args.steps, args.warmup, args.docs)
+    K = wl["K"]
+    out = None
+    if job.rank == 0:
         out = {
             "metric": "documents/sec per VB iteration",
-            "value": value, "unit": "docs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": wl["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic"
-            if args.workload != "ap" else "associated-press (parsed fixture)",
-            "config": {"workload": wl["label"], "docs_total": D_total, "nnz_total": nnz_total,
-                       "docs_per_gpu": D_local, "nnz_per_gpu": nnz_local, "tokens_per_gpu": tokens_local,
-                       "K": K, "V": V, "inner_iterations_cap": 50, "parallelism": "dp%d" % world,
-                       "step": "e_step + sstats all-reduce + device m_step + alpha update"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "estep document kernels (one E-step's launches)",
-                         "kernel_ms": kernel_avg_ms, "algorithmic_bytes": B},
-            "joint_log_likelihood": joint,
+            "value": rec["value"], "unit": "docs/s", "n_gpus": job.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+            "scaling": rec["scaling"], "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if args.workload.startswith("synth") else "parsed corpus fixture (tests/golden)",
+            "config": rec["config"], "roofline": rec["roofline"],
+            "joint_log_likelihood": rec["joint_log_likelihood"], "startup": rec["startup"],
         }
-        # the honest companion: the kernel is fp64-VALU / latency bound, not HBM bound.
-        # flops of the inner loops actually executed = sum_d I_d * 4 * N_d * K (two mat-vecs per iteration).
         try:
-            import ctypes
-            iters = np.empty(D_local, dtype=np.int32)
-            ctx._check(ctx._lib.pylda_get_doc_values(ctx._h, vb._train_corpus._h, None, None,
-                                                     iters.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
-            work = float(np.dot(iters.astype(np.float64), np.diff(ptr).astype(np.float64))) * 4.0 * K
-            tflops = work / (kernel_avg_ms * 1e-3) / 1e12 if kernel_avg_ms > 0 else 0.0
-            out["roofline_fp64"] = {"bound": "fp64 vector FMA", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
-                                    "flops_per_launch": work, "mean_inner_iterations": float(iters.mean())}
+            out["roofline_fp64"] = fp64_companion(ctx, vb, wl["ptr"], K, rec["roofline"]["kernel_ms_documents"])
         except Exception as exc:
             out["roofline_fp64"] = {"error": str(exc)}
-        # ---- CPU baseline + per-document log-likelihood delta on a bounded sample ----
-        if not args.no_cpu_baseline:
-            alpha = vb._alpha_alpha.copy()
-            eta = vb._eta.copy()
-            rate, n, cpu_ll = cpu_baseline(alpha, eta, ptr, ids, cts, args.cpu_seconds, 2000)
-            sample = ctx.corpus(ptr[:n + 1], ids[:ptr[n]], cts[:ptr[n]])
-            gpu = ctx.estep_host(sample, alpha, eta)
-            sample.close()
-            delta = np.abs(gpu["doc_ll"] - cpu_ll) / np.abs(cpu_ll)
-            out["cpu_baseline"] = {
-                "value": rate, "unit": "docs/s", "cores": 1, "kind": "port",
-                "sample": "first %d documents of rank 0's corpus, numpy/scipy restatement of "
-                          "variational_bayes.py:132-216 (oracle/vb_numpy.py), single thread; "
-                          "host has %d cores" % (n, os.cpu_count()),
-                "c_port_docs_per_s": c_oracle_rate(alpha, eta, ptr, ids, cts, n),
-            }
-            out["ll_delta"] = {"max_rel": float(delta.max()), "median_rel": float(np.median(delta)),
-                               "docs": int(n), "bar": 1e-5}
-            out["speedup_vs_cpu"] = value / rate
-        # ---- cfg 2 (associated-press K=10) alongside: speed-up target and parity ----
-        if args.workload != "ap" and not args.no_ap_extra and world == 1:
-            try:
-                out["ap_k10"] = ap_extra(_capi, args)
-            except Exception as exc:            # the fixture may be absent in a stripped tree
-                out["ap_k10"] = {"error": str(exc)}
+        if not args.no_cpu_baseline and job.world == 1:
+            out.update(cpu_leg(ctx, vb, wl, args, args.cpu_seconds, 2000, rec["value"]))
+    release(vb)
+    del vb, ctx, wl
+
+    extras = not args.no_extras and args.workload == "synth100k"
+    if extras:
+        # ---- cfg 4 (1M documents, K=256) alongside, every N: strong scaling + its own roofline ----
+        try:
+            rec4, vb4, ctx4, wl4 = measure(job, args, "synth1m", 3, 2, args.extra_docs)
+            if job.rank == 0:
+                sub = {"value": rec4["value"], "unit": "docs/s", "n_gpus": job.world, "steps": 3, "warmup": 2,
+                       "ms_per_step": rec4["ms_per_step"], "scaling": "strong", "config": rec4["config"],
+                       "roofline": rec4["roofline"], "startup": rec4["startup"]}
+                try:
+                    sub["roofline_fp64"] = fp64_companion(ctx4, vb4, wl4["ptr"], wl4["K"],
+                                                          rec4["roofline"]["kernel_ms_documents"])
+                except Exception as exc:
+                    sub["roofline_fp64"] = {"error": str(exc)}
+                if not args.no_cpu_baseline and job.world == 1:
+                    sub.update(cpu_leg(ctx4, vb4, wl4, args, min(args.cpu_seconds, 10.0), 400, rec4["value"]))
+                out["synth1m"] = sub
+            release(vb4)
+            del vb4, ctx4, wl4
+        except AssertionError:
+            raise
+        except Exception as exc:
+            if job.group is not None:
+                raise
+            out["synth1m"] = {"error": repr(exc)}
+    if job.rank == 0:
+        if extras and job.world == 1:
+            from pylda_amd import _capi
+            for key, fn in (("ap_k10", ap_extra), ("nips_k500", nips_extra)):
+                try:
+                    out[key] = fn(_capi, args)
+                except Exception as exc:            # the fixture may be absent in a stripped tree
+                    out[key] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
-    if group is not None:
+    if job.group is not None:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launcher_argv(gpus, argv):
+    """Command line that runs this script as `gpus` ranks of one node (rendezvous on 127.0.0.1)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def ap_extra(_capi, args):
@@ -275,14 +420,19 @@ def ap_extra(_capi, args):
         ctx.estep(corpus)
     ctx.synchronize()
     reps = 20
+    ctx.set_profiling(True)
+    ctx.kernel_time()
     t0 = time.perf_counter()
     for _ in range(reps):
         ctx.estep(corpus)
         ctx.estep_results(corpus)
     gpu_rate = 2000 * reps / (time.perf_counter() - t0)
+    doc_ms, ss_ms, calls = ctx.kernel_time()
+    ctx.set_profiling(False)
     doc_ll, _, iters = ctx.get_doc_values(corpus)
     delta = np.abs(doc_ll - g["doc_ll"]) / np.abs(g["doc_ll"])
     out = {"gpu_docs_per_s": gpu_rate, "estep_ms": 2000.0 / gpu_rate * 1e3,
+           "kernel_ms_documents": doc_ms / max(1, calls), "kernel_ms_sstats": ss_ms / max(1, calls),
            "max_rel_ll_delta_vs_reference": float(delta.max()),
            "iters_equal_fraction": float(np.mean(iters == g["iters"]))}
     if not args.no_cpu_baseline:
@@ -290,6 +440,66 @@ def ap_extra(_capi, args):
         out.update({"cpu_docs_per_s": rate, "cpu_sample_docs": n, "speedup": gpu_rate / rate})
     corpus.close()
     ctx.close()
+    return out
+
+
+def nips_extra(_capi, args):
+    """BASELINE.json cfg 5 on one GPU: parsed/nips.88-05, K=500, 50 learning() iterations from the reference's
+    seeded start; E-step time / docs/s, joint log-likelihood and held-out per-token log-likelihood after 50
+    iterations against the reference's own trace (tests/golden/nips_trace_k500.npz)."""
+    from pylda_amd.variational_bayes import VariationalBayes
+    g = np.load(os.path.join(ROOT, "tests", "golden", "nips_trace_k500.npz"))
+    K, V = int(g["K"]), len(g["words"])
+    ptr, ids, cts = g["doc_ptr"].astype(np.int64), g["term_id"].astype(np.int32), g["term_ct"].astype(np.int32)
+    test = (g["test_doc_ptr"].astype(np.int64), g["test_term_id"].astype(np.int32), g["test_term_ct"].astype(np.int32))
+    np.random.seed(int(g["seed"]))
+    m = VariationalBayes()
+    m._verbose = False
+    m._initialize_parsed(ptr, ids, cts, V, K, 1.0 / K, 1.0 / V)      # eta: the seeded draw of variational_bayes.py:95
+    ctx = m._context()
+    D, nnz = len(ptr) - 1, int(ptr[-1])
+    n_iter = min(50, len(g["joint_ll"]))
+    m.learning()
+    ctx.synchronize()
+    ctx.set_profiling(True)
+    ctx.kernel_time()
+    t0 = time.perf_counter()
+    for _ in range(n_iter - 1):
+        joint = m.learning()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    doc_ms, ss_ms, calls = ctx.kernel_time()
+    classes = m._train_corpus.plan()
+    ctx.set_profiling(False)
+    calls = max(1, calls)
+    wll, _ = m.e_step(test)
+    ref_joint = float(g["joint_ll"][n_iter - 1])
+    heldout = {int(it): v for it, v in g["heldout"]}
+    tokens = int(g["test_tokens"])
+    B = algorithmic_bytes(nnz, D, K)
+    kernel_ms = (doc_ms + ss_ms) / calls
+    for c in classes:
+        c["kernel_ms"] /= calls
+    out = {"docs_per_s": D * (n_iter - 1) / elapsed, "ms_per_step": elapsed / (n_iter - 1) * 1e3, "iterations": n_iter,
+           "config": {"workload": "parsed/nips.88-05, K=500, train = first 2235 documents, test = last 248",
+                      "docs": D, "nnz": nnz, "K": K, "V": V},
+           "roofline": {"bound": "hbm", "achieved": B / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": B / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": kernel_ms,
+                        "kernel_ms_documents": doc_ms / calls, "kernel_ms_sstats": ss_ms / calls,
+                        "algorithmic_bytes": B, "launch_classes": classes,
+                        "note": "2235 workgroup-documents on 256 CUs: latency-bound, not a bandwidth measurement"},
+           "joint_log_likelihood": joint, "reference_joint_log_likelihood": ref_joint,
+           "joint_rel_delta": abs(joint - ref_joint) / abs(ref_joint),
+           "heldout_per_token_log_likelihood": wll / tokens}
+    if n_iter in heldout:
+        out["reference_heldout_per_token_log_likelihood"] = heldout[n_iter] / tokens
+        out["heldout_rel_delta"] = abs(wll - heldout[n_iter]) / abs(heldout[n_iter])
+    if not args.no_cpu_baseline:
+        rate, n, _ = cpu_baseline(m._alpha_alpha.copy(), m._eta.copy(), ptr, ids, cts, min(args.cpu_seconds, 10.0), 200)
+        out["cpu_baseline"] = {"value": rate, "unit": "docs/s", "cores": 1, "kind": "port",
+                               "sample": "first %d training documents, numpy/scipy restatement, single thread" % n}
+        out["speedup_vs_cpu"] = out["docs_per_s"] / rate
+    release(m)
     return out
 
 

@@ -57,11 +57,16 @@ int pylda_create(int device, int K, int V, pylda_ctx** out);
 void pylda_destroy(pylda_ctx* ctx);
 const char* pylda_last_error(const pylda_ctx* ctx);
 
-/* Run the context's work on an existing HIP stream (e.g. torch's current
- * stream, so that an RCCL all-reduce issued through torch.distributed is
- * ordered after the E-step without a host sync).  NULL restores the
- * context's own stream.  The caller keeps the stream alive. */
+/* Run the context's work on an existing HIP stream (e.g. a torch stream, so
+ * that an RCCL all-reduce issued through torch.distributed on the same stream
+ * is ordered after the E-step without a host sync).  As everywhere in HIP, a
+ * NULL handle names the device's default (null) stream - which is what
+ * torch.cuda.current_stream().cuda_stream is for torch's default stream.
+ * pylda_use_own_stream returns to the context's private (non-blocking)
+ * stream.  Both drain the stream in use before switching; the caller keeps a
+ * stream it handed over alive. */
 int pylda_set_stream(pylda_ctx* ctx, void* hip_stream);
+int pylda_use_own_stream(pylda_ctx* ctx);
 int pylda_synchronize(pylda_ctx* ctx);
 
 /* Upload a parsed corpus: the (word_ids, word_cts) lists parse_data builds
@@ -141,12 +146,25 @@ int pylda_mark_device_state(pylda_ctx* ctx, int have_eta, int have_sstats);
 int pylda_mstep(pylda_ctx* ctx, pylda_corpus* corpus, const double* beta_v,
                 double* topic_log_likelihood, double* alpha_ss_k);
 
-/* Profiling: when enabled, every pylda_estep brackets its document kernels
- * with HIP events on the launch stream.  pylda_kernel_time returns the
- * accumulated document-kernel time (ms) and launch count since the last
- * reset, and resets them. */
+/* Profiling: when enabled, every pylda_estep brackets (HIP events on the launch
+ * streams) its document kernels as a group, each launch class on its own, and
+ * the sufficient-statistics pass (gather + finalize).  pylda_kernel_time
+ * returns the accumulated group times (ms) and the number of E-steps since the
+ * last reset, and resets them. */
 int pylda_set_profiling(pylda_ctx* ctx, int enabled);
-int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, int64_t* estep_calls);
+int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, double* sstats_kernel_ms,
+                      int64_t* estep_calls);
+
+/* The launch schedule of a corpus: documents are bucketed by distinct-term
+ * count into launch classes (one kernel instantiation each; the classes of one
+ * E-step run concurrently on separate streams).  Fills up to `capacity`
+ * entries per array (any may be NULL): kernel variant index (see
+ * "force_variant"), its geometry code, documents and distinct (doc, term)
+ * pairs in the class, and the profiled kernel time accumulated for the class
+ * since the last call (ms; reset by the call).  Returns the number of classes
+ * (>= 0) or a negative status. */
+int pylda_corpus_plan(pylda_corpus* corpus, int32_t capacity, int32_t* variant, int32_t* geometry,
+                      int64_t* documents, int64_t* terms, double* kernel_ms);
 
 /* Tuning / test options:
  *   "doc_values"     1 (default): pylda_get_doc_values returns complete per-document
@@ -156,10 +174,11 @@ int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, int64_t* estep_call
  *                    second table gather per document; doc_ll[] is then unavailable;
  *   "force_logspace" 0|1  run every document through the log-space
  *                         safety-net kernel (the reference's formulation);
- *   "force_variant"  -1 (automatic) or a kernel variant index 0..9 (generic LDS 64/256/512
- *                    threads, generic global, slab, column, quilt, streaming, hybrid, wide tiered);
+ *   "force_variant"  -1 (automatic) or a kernel variant index: 0..2 generic LDS 64/256/512
+ *                    threads, 3 generic global, 4 slab, 6 quilt, 7 streaming, 8 hybrid, 9 wide
+ *                    tiered (5 was round 1's column kernel, removed);
  *                    a variant that cannot take a document falls back to the automatic choice;
- *   "quilt_odd", "quilt12", "column_waves", "gather_rows"  A/B switches of kernel geometry
+ *   "quilt_odd", "quilt12", "gather_rows"  A/B switches of kernel geometry
  *                    ("Tried and measured"). */
 int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value);
 
@@ -168,8 +187,12 @@ int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digam
                        double* lgamma_out);
 
 /* Native corpus ingest: parse_data (variational_bayes.py:98-130) without the Python
- * interpreter.  `text` holds the documents, one per line ('\n'), tokens separated by
- * blanks; `vocab` holds the word types, one per line, in id order (id = line number).
+ * interpreter.  `text` holds the documents, each ended by the byte `doc_separator`
+ * ('\n' for the contents of a train.dat file; the Python binding joins the caller's strings
+ * with a byte that occurs in none of them) except possibly the last; tokens are separated by
+ * the white space Python's str.split() splits on (the Unicode set, UTF-8 encoded - a '\n'
+ * inside a document is just white space when it is not the separator).  `vocab` holds the
+ * word types, one per line ('\n'), in id order (id = index among the distinct lines).
  * Rules kept from the reference: tokens not in the vocabulary are skipped (:108-109),
  * documents left without tokens are dropped (:116-118); the caller lower-cases/strips
  * lines beforehand if it wants launch_train.py:106 semantics (ASCII lower-casing can be
@@ -177,9 +200,9 @@ int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digam
  * order (what the reference's dict gives on CPython >= 3.7).
  * Two-call protocol: call with term_id == NULL to get the sizes (*n_docs, *nnz), then
  * with buffers of n_docs+1 / nnz / nnz elements.  Pure host code: no GPU needed. */
-int pylda_parse_corpus(const char* text, int64_t text_bytes, const char* vocab, int64_t vocab_bytes,
-                       int lowercase, int64_t* n_docs, int64_t* nnz, int64_t* doc_ptr,
-                       int32_t* term_id, int32_t* term_ct, int64_t* dropped_docs);
+int pylda_parse_corpus(const char* text, int64_t text_bytes, int doc_separator, const char* vocab,
+                       int64_t vocab_bytes, int lowercase, int64_t* n_docs, int64_t* nnz,
+                       int64_t* doc_ptr, int32_t* term_id, int32_t* term_ct, int64_t* dropped_docs);
 
 /* Test hook: out[i] = exp(digamma(x[i]) - c), the fused form the inner loop uses. */
 int pylda_test_expdigamma(pylda_ctx* ctx, int64_t n, const double* x, double c, double* out);

@@ -25,6 +25,7 @@ SIGNATURES = {
     "pylda_destroy": (None, [_vp]),
     "pylda_last_error": (ctypes.c_char_p, [_vp]),
     "pylda_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "pylda_use_own_stream": (ctypes.c_int, [_vp]),
     "pylda_synchronize": (ctypes.c_int, [_vp]),
     "pylda_corpus_create": (ctypes.c_int, [_vp, ctypes.c_int64, _c_int64_p, _c_int32_p, _c_int32_p,
                                            ctypes.POINTER(_vp)]),
@@ -49,11 +50,13 @@ SIGNATURES = {
     "pylda_mark_device_state": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "pylda_mstep": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, _c_double_p]),
     "pylda_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
-    "pylda_kernel_time": (ctypes.c_int, [_vp, _c_double_p, _c_int64_p]),
+    "pylda_kernel_time": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_int64_p]),
+    "pylda_corpus_plan": (ctypes.c_int, [_vp, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int64_p, _c_int64_p,
+                                         _c_double_p]),
     "pylda_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
-    "pylda_parse_corpus": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64,
-                                          ctypes.c_int, _c_int64_p, _c_int64_p, _c_int64_p, _c_int32_p,
-                                          _c_int32_p, _c_int64_p]),
+    "pylda_parse_corpus": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int, ctypes.c_char_p,
+                                          ctypes.c_int64, ctypes.c_int, _c_int64_p, _c_int64_p, _c_int64_p,
+                                          _c_int32_p, _c_int32_p, _c_int64_p]),
     "pylda_test_expdigamma": (ctypes.c_int, [_vp, ctypes.c_int64, _c_double_p, ctypes.c_double, _c_double_p]),
     "pylda_test_special": (ctypes.c_int, [_vp, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p]),
 }
@@ -122,27 +125,43 @@ class PyldaError(RuntimeError):
         self.status = status
 
 
+def _join_documents(lines):
+    """One bytes object + the separator byte: a byte that occurs in no document (so a document
+    that itself contains line breaks stays ONE document, as in the reference's per-string loop)."""
+    for sep in ("\x00", "\x01", "\x02", "\x03"):      # never white space, (almost) never in text
+        text = sep.join(lines)
+        if text.count(sep) == max(len(lines) - 1, 0):
+            return text.encode("utf-8", "surrogatepass"), ord(sep)
+    # every candidate occurs somewhere: 0xFF is not a byte of any UTF-8 sequence
+    return b"\xff".join(l.encode("utf-8", "surrogatepass") for l in lines), 0xFF
+
+
 def parse_corpus(lines, vocabulary, lowercase=False):
     """Native parse_data (variational_bayes.py:98-130): documents (iterable of str) and the
-    vocabulary in id order -> CSR (doc_ptr int64, term_id int32, term_ct int32), #dropped."""
+    vocabulary in id order -> CSR (doc_ptr int64, term_id int32, term_ct int32), #dropped.
+
+    A vocabulary entry that is empty or contains white space can never equal a token of
+    str.split(); it keeps its id (a placeholder no token can match takes its line)."""
     lib = load()
-    text = "\n".join(lines).encode("utf-8")
-    vocab = "\n".join(vocabulary).encode("utf-8")
-    n_docs, nnz, dropped = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
-    rc = lib.pylda_parse_corpus(text, len(text), vocab, len(vocab), 1 if lowercase else 0,
+    lines = list(lines)
+    text, sep = _join_documents(lines)
+    vocab = b"\n".join(w.encode("utf-8", "surrogatepass") if len(w.split()) == 1 and w == w.strip()
+                       else b"\xfe%d" % i for i, w in enumerate(vocabulary))
+    n_docs, nnz = ctypes.c_int64(0), ctypes.c_int64(0)
+    rc = lib.pylda_parse_corpus(text, len(text), sep, vocab, len(vocab), 1 if lowercase else 0,
                                 ctypes.byref(n_docs), ctypes.byref(nnz), None, None, None, None)
     if rc != 0:
         raise PyldaError(rc, "pylda_parse_corpus (sizing pass)")
     doc_ptr = np.zeros(n_docs.value + 1, dtype=np.int64)
     term_id = np.zeros(max(nnz.value, 1), dtype=np.int32)
     term_ct = np.zeros(max(nnz.value, 1), dtype=np.int32)
-    rc = lib.pylda_parse_corpus(text, len(text), vocab, len(vocab), 1 if lowercase else 0,
+    rc = lib.pylda_parse_corpus(text, len(text), sep, vocab, len(vocab), 1 if lowercase else 0,
                                 ctypes.byref(n_docs), ctypes.byref(nnz),
                                 doc_ptr.ctypes.data_as(_c_int64_p), term_id.ctypes.data_as(_c_int32_p),
-                                term_ct.ctypes.data_as(_c_int32_p), ctypes.byref(dropped))
+                                term_ct.ctypes.data_as(_c_int32_p), None)
     if rc != 0:
         raise PyldaError(rc, "pylda_parse_corpus")
-    return doc_ptr, term_id[:nnz.value], term_ct[:nnz.value], dropped.value
+    return doc_ptr, term_id[:nnz.value], term_ct[:nnz.value], len(lines) - n_docs.value
 
 
 def device_count():
@@ -195,7 +214,11 @@ class Context(object):
         self._check(self._lib.pylda_set_alpha(self._h, _dp(_f64(alpha, (self.K,), "alpha"))))
 
     def set_stream(self, hip_stream):
+        """Run on the HIP stream with this handle; 0 / None is the device's default (null) stream."""
         self._check(self._lib.pylda_set_stream(self._h, _vp(hip_stream) if hip_stream else None))
+
+    def use_own_stream(self):
+        self._check(self._lib.pylda_use_own_stream(self._h))
 
     def synchronize(self):
         self._check(self._lib.pylda_synchronize(self._h))
@@ -231,9 +254,11 @@ class Context(object):
         self._check(self._lib.pylda_get_gamma(self._h, corpus._h, _dp(out)))
         return out
 
-    def get_doc_values(self, corpus):
-        ll = np.empty(corpus.D, dtype=np.float64)
-        wll = np.empty(corpus.D, dtype=np.float64)
+    def get_doc_values(self, corpus, want_ll=True):
+        """(doc_ll, doc_words_ll, iters) of the last E-step; want_ll=False skips the per-document
+        likelihoods (unavailable after an E-step on the training fast path, option doc_values=0)."""
+        ll = np.empty(corpus.D, dtype=np.float64) if want_ll else None
+        wll = np.empty(corpus.D, dtype=np.float64) if want_ll else None
         iters = np.empty(corpus.D, dtype=np.int32)
         self._check(self._lib.pylda_get_doc_values(self._h, corpus._h, _dp(ll), _dp(wll), _ip(iters)))
         return ll, wll, iters
@@ -283,9 +308,10 @@ class Context(object):
         self._check(self._lib.pylda_set_profiling(self._h, 1 if enabled else 0))
 
     def kernel_time(self):
-        ms, calls = ctypes.c_double(0), ctypes.c_int64(0)
-        self._check(self._lib.pylda_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(calls)))
-        return ms.value, calls.value
+        """(document-kernel ms, statistics-pass ms, E-steps) accumulated since the last call."""
+        ms, ss, calls = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+        self._check(self._lib.pylda_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(ss), ctypes.byref(calls)))
+        return ms.value, ss.value, calls.value
 
     def test_expdigamma(self, x, c):
         x = _f64(x)
@@ -325,6 +351,25 @@ class Corpus(object):
 
     def gamma_device_ptr(self):
         return int(self._ctx._lib.pylda_gamma_device(self._h) or 0)
+
+    VARIANT_NAMES = {0: "generic64", 1: "generic256", 2: "generic512", 3: "generic_global", 4: "slab",
+                     6: "quilt", 7: "qstream", 8: "qhybrid", 9: "qwide"}
+
+    def plan(self):
+        """Launch classes of this corpus: list of dicts (kernel, geometry, documents, terms, kernel_ms)."""
+        lib = self._ctx._lib
+        n = lib.pylda_corpus_plan(self._h, 0, None, None, None, None, None)
+        if n < 0:
+            self._ctx._check(n)
+        variant, geometry = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        documents, terms, ms = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.float64)
+        rc = lib.pylda_corpus_plan(self._h, n, _ip(variant), _ip(geometry), documents.ctypes.data_as(_c_int64_p),
+                                   terms.ctypes.data_as(_c_int64_p), _dp(ms))
+        if rc < 0:
+            self._ctx._check(rc)
+        return [{"kernel": self.VARIANT_NAMES.get(int(variant[i]), str(int(variant[i]))), "geometry": int(geometry[i]),
+                 "documents": int(documents[i]), "terms": int(terms[i]), "kernel_ms": float(ms[i])}
+                for i in range(n)]
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):

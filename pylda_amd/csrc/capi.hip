@@ -15,15 +15,12 @@
 #include <new>
 #include <numeric>
 #include <string>
-#include <string_view>
-#include <unordered_map>
 #include <vector>
 
 #include "estep_common.h"
 #include "estep_generic.h"
 #include "estep_logspace.h"
 #include "estep_slab.h"
-#include "estep_column.h"
 #include "estep_quilt.h"
 #include "estep_qstream.h"
 #include "estep_qhybrid.h"
@@ -44,7 +41,7 @@ enum Variant : int {
     kGeneric512 = 2,   // 8 wavefronts / document, tile in LDS (up to the whole 160 KiB)
     kGenericGlobal = 3, // tile larger than LDS: rows re-read from the table
     kSlab = 4,          // tile in registers, word-major lanes (estep_slab.h)
-    kColumn = 5,        // tile in registers, topic-major lanes (estep_column.h)
+    kRetired5 = 5,      // (the topic-major column kernel of round 1: measured 2x slower than the quilt layout, removed)
     kQuilt = 6,         // tile in registers, 4 x 16 word-group x topic lanes (estep_quilt.h)
     kQstream = 7,       // tile streamed from L2 twice per iteration, quilt lanes (estep_qstream.h)
     kQhybrid = 8,       // tile split over registers / LDS / streamed remainder (estep_qhybrid.h)
@@ -93,23 +90,27 @@ struct pylda_ctx {
     double* d_beta = nullptr;       // V
     double* d_small = nullptr;      // scalars + K-vectors scratch
     double* d_partial = nullptr;    // alpha-ss partials
-    int32_t* d_flag_count = nullptr;
+    std::vector<double> h_beta;     // the beta last handed to pylda_mstep (its lgamma sums are cached)
+    double beta_sum = 0.0, beta_lgamma_sum = 0.0;
 
     std::vector<double> h_alpha;
     bool have_eta = false, have_alpha = false, have_sstats = false;
     int force_logspace = 0;
     int force_variant = -1;
-    int column_waves = 8;
     int quilt12 = 0;
     int gather_rows = 1;            // whole-row gather kernel for ldk 64 / 128 / 256
     int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
     int doc_values = 1;             // 1: per-document log-likelihoods complete (see EstepParams::want_doc_ll)
     int plan_epoch = 0;
+    bool exact_stop = false;        // this E-step's threshold is outside the fixed-point stop test's range
 
+    // profiling (pylda_set_profiling): HIP events on the launch streams
+    struct Bracket { hipEvent_t a, b; int slot; };   // slot -1: document kernels, -2: statistics pass, >= 0: launch class
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    std::vector<Bracket> pending_events;
     std::vector<hipEvent_t> event_pool;
-    double doc_kernel_ms = 0.0;
+    double doc_kernel_ms = 0.0, sstats_kernel_ms = 0.0;
+    std::vector<double> class_ms;   // per launch class of the last profiled corpus
     int64_t estep_calls = 0;
 
     std::string err;
@@ -129,6 +130,7 @@ struct pylda_corpus {
     int32_t* d_iters = nullptr;
     int32_t* d_status = nullptr;
     int32_t* d_flag_list = nullptr;
+    int32_t* d_flag_count = nullptr;   // documents the safety net redid in the last E-step over THIS corpus
     double* d_scalars = nullptr;   // [0] doc ll, [1] words ll, [2] corpus entropy term (fast path)
     double* d_entropy_partial = nullptr;
     bool last_doc_values = true;
@@ -148,6 +150,7 @@ struct pylda_corpus {
     std::vector<int32_t> h_terms_sorted;  // distinct-term counts in schedule order
     std::vector<Launch> plan;
     int plan_epoch = 0;
+    bool plan_exact = false;       // the plan avoids the kernels with the fixed-point stop test
     bool estep_done = false;
     int last_heldout = 0;
 };
@@ -208,17 +211,6 @@ SlabGeom slab_geom_for(const pylda_ctx* ctx, int n)
     return {0, 0, 0};
 }
 
-// Column (topic-major, register-resident) kernel: words per wavefront, or 0.
-// column_waves: wavefronts per document (option "column_waves", 8 or 16).
-int column_rnw_for(const pylda_ctx* ctx, int n)
-{
-    if (ctx->ldk != 64 && ctx->ldk != 128) return 0;
-    const int W = ctx->column_waves;
-    for (int rnw = 8; rnw <= (W == 16 ? 16 : 32); rnw *= 2)
-        if (n <= W * rnw) return rnw;
-    return 0;
-}
-
 // Quilt (2-D lanes, register-resident) kernel geometry: wavefronts per document and
 // words per lane (W * 4 * RWL >= n), or W = 0.  12 wavefronts x 4 words per lane keeps a
 // 129..192-term document at 149 VGPRs = 3 wavefronts per SIMD instead of 2.
@@ -258,13 +250,15 @@ bool qstream_ok(const pylda_ctx* ctx, int n) { return ctx->ldk % 64 == 0 && ctx-
 // Decide the kernel variant for a document with n distinct terms.
 int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
 {
+    // The register-resident and streaming kernels decide convergence on a 2^-40 fixed-point sum of
+    // |delta gamma_k|, each clipped to 1024 (estep_common.h change_fixed): equivalent to the
+    // reference's floating-point `mean <= threshold` (:187-189) while 2^-28 <= threshold*K < 1024.
+    // Outside that range (threshold 0: "run until nothing moves at all"; huge thresholds) the
+    // generic kernels, which compare in floating point, take the documents.
+    if (ctx->exact_stop) goto generic;
     if ((ctx->force_variant < 0 || ctx->force_variant == kQuilt) && quilt_geom_for(ctx, n).W > 0) {
         *lds_bytes = 0;
         return kQuilt;
-    }
-    if ((ctx->force_variant < 0 || ctx->force_variant == kColumn) && column_rnw_for(ctx, n) > 0) {
-        *lds_bytes = 0;
-        return kColumn;
     }
     if ((ctx->force_variant < 0 || ctx->force_variant == kSlab) && slab_geom_for(ctx, n).W > 0) {
         *lds_bytes = 0;
@@ -282,6 +276,7 @@ int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
         *lds_bytes = 0;
         return kQstream;
     }
+generic:
     const int K = ctx->K, stride = tile_stride_for(K);
     const size_t l64 = generic_lds_layout(K, n, stride, 64, false).total;
     const size_t l256 = generic_lds_layout(K, n, stride, 256, false).total;
@@ -309,6 +304,7 @@ void build_plan(pylda_corpus* c)
     pylda_ctx* ctx = c->ctx;
     c->plan.clear();
     c->plan_epoch = ctx->plan_epoch;
+    c->plan_exact = ctx->exact_stop;
     const int64_t D = c->D;
     int64_t i = 0;
     while (i < D) {
@@ -323,7 +319,6 @@ void build_plan(pylda_corpus* c)
             const int vj = choose_variant(ctx, c->h_terms_sorted[j], &lds_j);
             if (vj != v) break;
             if (v == kQuilt && quilt_rwl_for(ctx, c->h_terms_sorted[j]) != quilt_rwl_for(ctx, c->h_terms_sorted[i])) break;
-            if (v == kColumn && column_rnw_for(ctx, c->h_terms_sorted[j]) != column_rnw_for(ctx, c->h_terms_sorted[i])) break;
             if (v == kQwide && qwide_rounds_for(c->h_terms_sorted[j]) != qwide_rounds_for(c->h_terms_sorted[i])) break;
             if (v == kSlab) {
                 const SlabGeom gi = slab_geom_for(ctx, c->h_terms_sorted[i]), gj = slab_geom_for(ctx, c->h_terms_sorted[j]);
@@ -342,7 +337,6 @@ void build_plan(pylda_corpus* c)
         L.tile_stride = tile_stride_for(ctx->K);
         L.lds_bytes = lds_first;
         L.rn = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RN
-             : v == kColumn ? column_rnw_for(ctx, c->h_terms_sorted[i])
              : v == kQuilt ? quilt_rwl_for(ctx, c->h_terms_sorted[i])
              : v == kQwide ? qwide_rounds_for(c->h_terms_sorted[i]) : 0;
         L.rk = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RK : 0;
@@ -391,30 +385,6 @@ int launch_slab_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 #undef SLAB_RN32
 #undef SLAB_CASE
     return fail(ctx, PYLDA_ERR_STATE, "no slab kernel for W=%d RK=%d RN=%d", W, L.rk, L.rn);
-}
-
-template <int W, int KR, int RNW>
-int launch_column(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
-{
-    auto kern = estep_column_kernel<W, KR, RNW>;
-    const size_t lds = ColumnLds<W, KR, RNW>::total;
-    if (lds > 64 * 1024)
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * W), lds, ctx->stream, p);
-    HIP_TRY(ctx, hipGetLastError());
-    return PYLDA_OK;
-}
-
-int launch_column_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
-{
-    const int KR = ctx->ldk / 64;
-#define COL_CASE(w_, kr_, rnw_) \
-    if (ctx->column_waves == w_ && KR == kr_ && L.rn == rnw_) return launch_column<w_, kr_, rnw_>(ctx, p, L);
-    COL_CASE(8, 1, 8) COL_CASE(8, 1, 16) COL_CASE(8, 1, 32) COL_CASE(8, 2, 8) COL_CASE(8, 2, 16) COL_CASE(8, 2, 32)
-    COL_CASE(16, 1, 8) COL_CASE(16, 1, 16) COL_CASE(16, 2, 8) COL_CASE(16, 2, 16)
-#undef COL_CASE
-    return fail(ctx, PYLDA_ERR_STATE, "no column kernel for KR=%d RNW=%d", KR, L.rn);
 }
 
 template <int W, int KRL, int RWL>
@@ -647,13 +617,15 @@ hipEvent_t take_event(pylda_ctx* ctx)
 
 void drain_events(pylda_ctx* ctx)
 {
-    for (auto& pr : ctx->pending_events) {
+    for (auto& br : ctx->pending_events) {
         float ms = 0.f;
-        if (hipEventSynchronize(pr.second) == hipSuccess &&
-            hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
-            ctx->doc_kernel_ms += ms;
-        ctx->event_pool.push_back(pr.first);
-        ctx->event_pool.push_back(pr.second);
+        if (hipEventSynchronize(br.b) == hipSuccess && hipEventElapsedTime(&ms, br.a, br.b) == hipSuccess) {
+            if (br.slot == -1) ctx->doc_kernel_ms += ms;
+            else if (br.slot == -2) ctx->sstats_kernel_ms += ms;
+            else if ((size_t)br.slot < ctx->class_ms.size()) ctx->class_ms[(size_t)br.slot] += ms;
+        }
+        ctx->event_pool.push_back(br.a);
+        ctx->event_pool.push_back(br.b);
     }
     ctx->pending_events.clear();
 }
@@ -742,7 +714,6 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     CREATE_TRY(dev_alloc(ctx, &ctx->d_alpha, (size_t)K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_small, (size_t)(4 * K + 16)));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_partial, (size_t)1024 * K));
-    CREATE_TRY(dev_alloc(ctx, &ctx->d_flag_count, (size_t)1));
     CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_sstats, 0, wk * sizeof(double), ctx->stream),
                       "hipMemsetAsync"));
 #undef CREATE_TRY
@@ -760,7 +731,7 @@ void pylda_destroy(pylda_ctx* ctx)
     dev_free(ctx->d_eta); dev_free(ctx->d_elog); dev_free(ctx->d_expElog); dev_free(ctx->d_expElog_elog); dev_free(ctx->d_sstats);
     dev_free(ctx->d_kv_scratch); dev_free(ctx->d_shift); dev_free(ctx->d_beta);
     dev_free(ctx->d_psi_rowsum); dev_free(ctx->d_topic_lse); dev_free(ctx->d_alpha);
-    dev_free(ctx->d_small); dev_free(ctx->d_partial); dev_free(ctx->d_flag_count);
+    dev_free(ctx->d_small); dev_free(ctx->d_partial);
     for (int i = 0; i < pylda_ctx::kAux; ++i) {
         if (ctx->aux_stream[i]) { (void)hipStreamSynchronize(ctx->aux_stream[i]); (void)hipStreamDestroy(ctx->aux_stream[i]); }
         if (ctx->join_event[i]) (void)hipEventDestroy(ctx->join_event[i]);
@@ -772,10 +743,21 @@ void pylda_destroy(pylda_ctx* ctx)
 
 int pylda_set_stream(pylda_ctx* ctx, void* hip_stream)
 {
+    // As everywhere in HIP, a NULL handle is the device's default ("null") stream - which is
+    // what torch.cuda.current_stream().cuda_stream reports for torch's default stream.
     if (!ctx) return PYLDA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return PYLDA_OK;
+}
+
+int pylda_use_own_stream(pylda_ctx* ctx)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
     return PYLDA_OK;
 }
 
@@ -792,8 +774,8 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kQwide)
-            return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld out of range", (long long)value);
+        if (value < -1 || value > kQwide || value == kRetired5)
+            return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld is not a kernel variant", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "gather_rows")) {
@@ -806,10 +788,6 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "doc_values")) {
         ctx->doc_values = value != 0;
-    } else if (!strcmp(name, "column_waves")) {
-        if (value != 8 && value != 16) return fail(ctx, PYLDA_ERR_INVALID, "column_waves must be 8 or 16");
-        ctx->column_waves = (int)value;
-        ctx->plan_epoch += 1;
     } else
         return fail(ctx, PYLDA_ERR_INVALID, "unknown option '%s'", name);
     return PYLDA_OK;
@@ -887,6 +865,7 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
     A(dev_alloc(ctx, &c->d_iters, (size_t)D));
     A(dev_alloc(ctx, &c->d_status, (size_t)D));
     A(dev_alloc(ctx, &c->d_flag_list, (size_t)D));
+    A(dev_alloc(ctx, &c->d_flag_count, (size_t)1));
     A(dev_alloc(ctx, &c->d_scalars, (size_t)4));
     A(dev_alloc(ctx, &c->d_entropy_partial, (size_t)(((int64_t)ctx->V * ctx->ldk + 255) / 256)));
     A(dev_alloc(ctx, &c->d_tfinal, (size_t)D * ctx->ldk));
@@ -923,7 +902,7 @@ void pylda_corpus_destroy(pylda_corpus* c)
     }
     dev_free(c->d_doc_ptr); dev_free(c->d_term_id); dev_free(c->d_term_ct); dev_free(c->d_order);
     dev_free(c->d_gamma); dev_free(c->d_doc_ll); dev_free(c->d_doc_wll); dev_free(c->d_iters);
-    dev_free(c->d_status); dev_free(c->d_flag_list); dev_free(c->d_scalars); dev_free(c->d_entropy_partial);
+    dev_free(c->d_status); dev_free(c->d_flag_list); dev_free(c->d_flag_count); dev_free(c->d_scalars); dev_free(c->d_entropy_partial);
     dev_free(c->d_tfinal); dev_free(c->d_rfinal); dev_free(c->d_post_doc); dev_free(c->d_post_pos);
     dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial);
     delete c;
@@ -995,7 +974,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     int rc = enqueue_prepare(ctx, heldout != 0);                      // :152-155
     if (rc != PYLDA_OK) return rc;
     if (!heldout && (rc = build_postings(c)) != PYLDA_OK) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_flag_count, 0, sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(c->d_flag_count, 0, sizeof(int32_t), ctx->stream));
 
     EstepParams p;
     p.K = K;
@@ -1027,13 +1006,23 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     p.rfinal = c->d_rfinal;
     p.status = c->d_status;
 
-    if (c->plan_epoch != ctx->plan_epoch) build_plan(c);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ctx->profiling) {
-        ev0 = take_event(ctx);
-        ev1 = take_event(ctx);
-        HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
+    {
+        const double span = tol * K;
+        ctx->exact_stop = !(span >= 3.725290298461914e-09 /* 2^-28 */ && span < 1024.0);
     }
+    if (c->plan_epoch != ctx->plan_epoch || c->plan_exact != ctx->exact_stop) build_plan(c);
+    auto open_bracket = [&](int slot, hipStream_t st) -> int {      // index into pending_events, or -1
+        if (!ctx->profiling) return -1;
+        pylda_ctx::Bracket br{take_event(ctx), take_event(ctx), slot};
+        if (!br.a || !br.b || hipEventRecord(br.a, st) != hipSuccess) return -1;
+        ctx->pending_events.push_back(br);
+        return (int)ctx->pending_events.size() - 1;
+    };
+    auto close_bracket = [&](int at, hipStream_t st) {
+        if (at >= 0) (void)hipEventRecord(ctx->pending_events[(size_t)at].b, st);
+    };
+    if (ctx->profiling && ctx->class_ms.size() != c->plan.size()) ctx->class_ms.assign(c->plan.size(), 0.0);
+    const int doc_bracket = open_bracket(-1, ctx->stream);
     if (ctx->force_logspace) {
         // test hook: mark every document for the log-space kernel
         std::vector<int32_t> ones((size_t)c->D, 1);
@@ -1048,40 +1037,43 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             HIP_TRY(ctx, hipEventRecord(ctx->fork_event, main_stream));
             for (int i = 0; i < used; ++i) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream[i], ctx->fork_event, 0));
         }
+        // the auxiliary streams rejoin the main stream on every path out of here, failures included
+        auto join = [&]() {
+            ctx->stream = main_stream;
+            for (int i = 0; i < used; ++i)
+                if (hipEventRecord(ctx->join_event[i], ctx->aux_stream[i]) == hipSuccess)
+                    (void)hipStreamWaitEvent(main_stream, ctx->join_event[i], 0);
+        };
         size_t launch_index = 0;
         for (const Launch& L : c->plan) {
-            if (fan_out) ctx->stream = ctx->aux_stream[launch_index++ % pylda_ctx::kAux];
+            const int slot = (int)launch_index;
+            if (fan_out) ctx->stream = ctx->aux_stream[launch_index % pylda_ctx::kAux];
+            ++launch_index;
             p.order = c->d_order + L.first;
             p.n_cap = L.n_cap;
             p.tile_stride = L.tile_stride;
+            const int class_bracket = open_bracket(slot, ctx->stream);
             switch (L.variant) {
             case kGeneric64: rc = launch_generic<64, false>(ctx, p, L); break;
             case kGeneric256: rc = launch_generic<256, false>(ctx, p, L); break;
             case kGeneric512: rc = launch_generic<512, false>(ctx, p, L); break;
             case kSlab: rc = launch_slab_any(ctx, p, L); break;
-            case kColumn: rc = launch_column_any(ctx, p, L); break;
             case kQuilt: rc = launch_quilt_any(ctx, p, L); break;
             case kQstream: rc = launch_qstream_any(ctx, p, L); break;
             case kQhybrid: rc = launch_qhybrid_any(ctx, p, L); break;
             case kQwide: rc = launch_qwide_any(ctx, p, L); break;
             default: rc = launch_generic<256, true>(ctx, p, L); break;
             }
+            close_bracket(class_bracket, ctx->stream);
             if (rc != PYLDA_OK) {
-                ctx->stream = main_stream;
+                join();
                 return rc;
             }
         }
-        ctx->stream = main_stream;
-        for (int i = 0; i < used; ++i) {
-            HIP_TRY(ctx, hipEventRecord(ctx->join_event[i], ctx->aux_stream[i]));
-            HIP_TRY(ctx, hipStreamWaitEvent(main_stream, ctx->join_event[i], 0));
-        }
+        join();
     }
-    if (ctx->profiling) {
-        HIP_TRY(ctx, hipEventRecord(ev1, ctx->stream));
-        ctx->pending_events.emplace_back(ev0, ev1);
-        ctx->estep_calls += 1;
-    }
+    close_bracket(doc_bracket, ctx->stream);
+    if (ctx->profiling) ctx->estep_calls += 1;
 
     // sufficient statistics (:207): gather pass over the postings, no atomics
     if (!heldout) {
@@ -1089,16 +1081,19 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             HIP_TRY(ctx, hipMemsetAsync(c->d_rfinal, 0, (size_t)c->nnz * sizeof(double), ctx->stream));
             HIP_TRY(ctx, hipMemsetAsync(c->d_tfinal, 0, (size_t)c->D * ctx->ldk * sizeof(double), ctx->stream));
         }
-        if ((rc = enqueue_sstats_gather(ctx, c)) != PYLDA_OK) return rc;
+        const int ss_bracket = open_bracket(-2, ctx->stream);
+        rc = enqueue_sstats_gather(ctx, c);
+        close_bracket(ss_bracket, ctx->stream);
+        if (rc != PYLDA_OK) return rc;
     }
     // safety net: documents the linear-space kernels flagged are redone in log space
     if (c->D > 0) {
         hipLaunchKernelGGL(flagged_collect_kernel, dim3((unsigned)((c->D + 255) / 256)), dim3(256), 0,
-                           ctx->stream, c->d_status, c->D, c->d_flag_list, ctx->d_flag_count);
+                           ctx->stream, c->d_status, c->D, c->d_flag_list, c->d_flag_count);
         p.order = nullptr;
         const unsigned grid = (unsigned)std::min<int64_t>(c->D, 4 * (int64_t)ctx->num_cu);
         hipLaunchKernelGGL(estep_logspace_kernel, dim3(grid), dim3(256), logspace_lds_bytes(K),
-                           ctx->stream, p, ctx->d_elog, ctx->d_sstats, c->d_flag_list, ctx->d_flag_count);
+                           ctx->stream, p, ctx->d_elog, ctx->d_sstats, c->d_flag_list, c->d_flag_count);
     }
     hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_doc_ll, c->D,
                        c->d_scalars);
@@ -1122,7 +1117,7 @@ int pylda_estep_results(pylda_ctx* ctx, pylda_corpus* c, double* document_log_li
     double sc[3] = {0, 0, 0};
     int32_t nflag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(sc, c->d_scalars, sizeof sc, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(&nflag, ctx->d_flag_count, sizeof nflag, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&nflag, c->d_flag_count, sizeof nflag, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // training fast path: the log B entropy term comes once per corpus from the statistics
     if (!c->last_doc_values) sc[0] -= sc[2];
@@ -1245,13 +1240,23 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* t
         return fail(ctx, PYLDA_ERR_STATE, "mstep: alpha statistics need the corpus of the last E-step");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int K = ctx->K, V = ctx->V;
-    double bsum = 0.0, blg = 0.0;
-    for (int v = 0; v < V; ++v) {
-        if (!(beta_v[v] > 0.0)) return fail(ctx, PYLDA_ERR_INVALID, "mstep: beta[%d]=%g", v, beta_v[v]);
-        bsum += beta_v[v];
-        blg += std::lgamma(beta_v[v]);
+    // beta is constant over a run: its lgamma sums (V host lgamma calls) and the device copy are
+    // refreshed only when the caller hands over different values
+    if (ctx->h_beta.size() != (size_t)V || memcmp(ctx->h_beta.data(), beta_v, (size_t)V * sizeof(double)) != 0) {
+        double bsum = 0.0, blg = 0.0;
+        for (int v = 0; v < V; ++v) {
+            if (!(beta_v[v] > 0.0)) return fail(ctx, PYLDA_ERR_INVALID, "mstep: beta[%d]=%g", v, beta_v[v]);
+            bsum += beta_v[v];
+            blg += std::lgamma(beta_v[v]);
+        }
+        ctx->h_beta.clear();            // stays empty if the copy below fails
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_beta, beta_v, (size_t)V * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host buffer is not retained
+        ctx->h_beta.assign(beta_v, beta_v + V);
+        ctx->beta_sum = bsum;
+        ctx->beta_lgamma_sum = blg;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_beta, beta_v, (size_t)V * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const double bsum = ctx->beta_sum, blg = ctx->beta_lgamma_sum;
     double* d_per_topic = ctx->d_small;          // K
     double* d_alpha_ss = ctx->d_small + K;       // K
     hipLaunchKernelGGL(mstep_topic_ll_kernel, dim3(K, kTopicChunks), dim3(256), 0, ctx->stream, ctx->d_eta, K, V,
@@ -1287,16 +1292,45 @@ int pylda_set_profiling(pylda_ctx* ctx, int enabled)
     return PYLDA_OK;
 }
 
-int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, int64_t* estep_calls)
+int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, double* sstats_kernel_ms, int64_t* estep_calls)
 {
     if (!ctx) return PYLDA_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     drain_events(ctx);
     if (doc_kernel_ms) *doc_kernel_ms = ctx->doc_kernel_ms;
+    if (sstats_kernel_ms) *sstats_kernel_ms = ctx->sstats_kernel_ms;
     if (estep_calls) *estep_calls = ctx->estep_calls;
-    ctx->doc_kernel_ms = 0.0;
+    ctx->doc_kernel_ms = ctx->sstats_kernel_ms = 0.0;
     ctx->estep_calls = 0;
     return PYLDA_OK;
+}
+
+int pylda_corpus_plan(pylda_corpus* c, int32_t capacity, int32_t* variant, int32_t* geometry, int64_t* documents,
+                      int64_t* terms, double* kernel_ms)
+{
+    if (!c || !c->ctx || capacity < 0) return PYLDA_ERR_INVALID;
+    pylda_ctx* ctx = c->ctx;
+    if (c->plan_epoch != ctx->plan_epoch || c->plan_exact != ctx->exact_stop) build_plan(c);
+    if (kernel_ms) {
+        if (hipSetDevice(ctx->device) == hipSuccess) drain_events(ctx);
+    }
+    const int n = (int)std::min<size_t>(c->plan.size(), (size_t)capacity);
+    for (int i = 0; i < n; ++i) {
+        const Launch& L = c->plan[(size_t)i];
+        if (variant) variant[i] = L.variant;
+        if (geometry) geometry[i] = L.rn;
+        if (documents) documents[i] = L.count;
+        if (terms) {
+            int64_t t = 0;
+            for (int64_t j = L.first; j < L.first + L.count; ++j) t += c->h_terms_sorted[(size_t)j];
+            terms[i] = t;
+        }
+        if (kernel_ms) {
+            kernel_ms[i] = (size_t)i < ctx->class_ms.size() ? ctx->class_ms[(size_t)i] : 0.0;
+            if ((size_t)i < ctx->class_ms.size()) ctx->class_ms[(size_t)i] = 0.0;
+        }
+    }
+    return (int)c->plan.size();
 }
 
 namespace {
@@ -1337,91 +1371,6 @@ int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digam
     }
     dev_free(dx); dev_free(dd); dev_free(dl);
     return rc;
-}
-
-int pylda_parse_corpus(const char* text, int64_t text_bytes, const char* vocab, int64_t vocab_bytes,
-                       int lowercase, int64_t* n_docs, int64_t* nnz, int64_t* doc_ptr,
-                       int32_t* term_id, int32_t* term_ct, int64_t* dropped_docs)
-{
-    if (!text || !vocab || text_bytes < 0 || vocab_bytes < 0 || !n_docs || !nnz) return PYLDA_ERR_INVALID;
-    const bool fill = term_id != nullptr;
-    if (fill && (!doc_ptr || !term_ct)) return PYLDA_ERR_INVALID;
-    try {
-        auto blank = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f'; };
-        // vocabulary: one type per line, id = line index (first occurrence wins, as parse_vocabulary)
-        std::unordered_map<std::string_view, int32_t> lookup;
-        lookup.reserve((size_t)(vocab_bytes / 6 + 16));
-        {
-            int32_t next = 0;
-            const char *p = vocab, *end = vocab + vocab_bytes;
-            while (p < end) {
-                const char* eol = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
-                if (!eol) eol = end;
-                const char *a = p, *b = eol;
-                while (a < b && blank(*a)) ++a;
-                while (b > a && blank(b[-1])) --b;
-                if (b > a && lookup.emplace(std::string_view(a, (size_t)(b - a)), next).second) ++next;
-                p = eol + 1;
-            }
-        }
-        std::string lowered;
-        std::vector<int32_t> slot;          // term id -> position in this document's list, -1 if absent
-        slot.assign(lookup.size(), -1);
-        std::vector<int32_t> ids, cts;
-        int64_t docs = 0, entries = 0, dropped = 0;
-        if (fill) doc_ptr[0] = 0;
-        const char *p = text, *end = text + text_bytes;
-        while (p < end) {
-            const char* eol = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
-            if (!eol) eol = end;
-            ids.clear();
-            cts.clear();
-            const char* q = p;
-            while (q < eol) {
-                while (q < eol && blank(*q)) ++q;
-                const char* tok = q;
-                while (q < eol && !blank(*q)) ++q;
-                if (q == tok) break;
-                std::string_view key(tok, (size_t)(q - tok));
-                if (lowercase) {
-                    lowered.assign(tok, q);
-                    for (char& ch : lowered)
-                        if (ch >= 'A' && ch <= 'Z') ch = (char)(ch - 'A' + 'a');
-                    key = lowered;
-                }
-                const auto hit = lookup.find(key);
-                if (hit == lookup.end()) continue;                         // :108-109
-                int32_t& at = slot[(size_t)hit->second];
-                if (at < 0) {
-                    at = (int32_t)ids.size();
-                    ids.push_back(hit->second);
-                    cts.push_back(1);
-                } else {
-                    cts[(size_t)at] += 1;
-                }
-            }
-            for (int32_t id : ids) slot[(size_t)id] = -1;
-            const bool had_text = eol > p || eol < end;                    // a line exists (even if empty)
-            if (!ids.empty()) {
-                if (fill) {
-                    memcpy(term_id + entries, ids.data(), ids.size() * sizeof(int32_t));
-                    memcpy(term_ct + entries, cts.data(), cts.size() * sizeof(int32_t));
-                    doc_ptr[docs + 1] = entries + (int64_t)ids.size();
-                }
-                entries += (int64_t)ids.size();
-                ++docs;
-            } else if (had_text) {
-                ++dropped;                                                 // :116-118
-            }
-            p = eol + 1;
-        }
-        *n_docs = docs;
-        *nnz = entries;
-        if (dropped_docs) *dropped_docs = dropped;
-    } catch (const std::bad_alloc&) {
-        return PYLDA_ERR_OOM;
-    }
-    return PYLDA_OK;
 }
 
 int pylda_test_expdigamma(pylda_ctx* ctx, int64_t n, const double* x, double c, double* out)

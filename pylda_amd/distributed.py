@@ -26,17 +26,50 @@ def device_tensor(ptr, shape, device):
 
 
 def bind_to_torch_stream(ctx):
+    """Run the context on a dedicated torch stream (kept on the context), so that collectives
+    issued through torch.distributed under `torch.cuda.stream(ctx._torch_stream)` are ordered
+    with the library's kernels on the device, no host synchronisation in between.  (Torch's
+    DEFAULT stream has handle 0, the legacy null stream: it would work - pylda_set_stream(NULL)
+    means exactly that stream - but it synchronises implicitly with every blocking stream of
+    the process; a stream of our own does not.)"""
     import torch
     torch.cuda.set_device(ctx.device)
-    ctx.set_stream(torch.cuda.current_stream(ctx.device).cuda_stream)
+    stream = torch.cuda.Stream(device=ctx.device)
+    ctx.set_stream(stream.cuda_stream)
+    ctx._torch_stream = stream          # keeps the stream alive as long as the context uses it
+    return stream
+
+
+def _stream_scope(ctx):
+    import contextlib
+    import torch
+    stream = getattr(ctx, "_torch_stream", None)
+    if stream is None:
+        # the context runs on its private stream: order by draining it (host sync)
+        ctx.synchronize()
+        return contextlib.nullcontext()
+    return torch.cuda.stream(stream)
 
 
 def allreduce_sstats(ctx, group=None):
-    """In-place RCCL all-reduce(sum) of the (V, K) sufficient statistics."""
+    """In-place all-reduce(sum) of the (V, ldk) sufficient statistics, ordered after the E-step's
+    kernels and before whatever the context enqueues next (the M-step).
+
+    RCCL (backend "nccl"): zero-copy on the library's device buffer.  Any other backend (gloo in
+    the single-GPU multi-rank tests): staged through a host copy on the same stream."""
     import torch
     import torch.distributed as dist
     t = device_tensor(ctx.sstats_device_ptr(), (ctx.sstats_elements(),), torch.device("cuda", ctx.device))
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    with _stream_scope(ctx):
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        else:
+            host = t.cpu()                                   # waits for the E-step on this stream
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(host)
+            torch.cuda.current_stream(ctx.device).synchronize()   # `host` is freed on return
+        if getattr(ctx, "_torch_stream", None) is None:
+            torch.cuda.current_stream(ctx.device).synchronize()
     ctx.mark_device_state(have_sstats=1)
     return t
 

@@ -60,6 +60,11 @@ class VariationalBayes(Inferencer):
         if self._gamma_host_stale:
             self._gamma_host = self._ctx.get_gamma(self._train_corpus)
             self._gamma_host_stale = False
+        elif self._gamma_host is None and self.__dict__.get("_gamma_init_pending"):
+            # variational_bayes.py:92 (D x K doubles nothing on the hot path reads: built on demand)
+            self._gamma_host = (numpy.zeros((self._number_of_documents, self._number_of_topics))
+                                + self._alpha_alpha[numpy.newaxis, :]
+                                + 1.0 * self._number_of_types / self._number_of_topics)
         return self._gamma_host
 
     @_gamma.setter
@@ -67,6 +72,7 @@ class VariationalBayes(Inferencer):
         self._gamma_host = value
         self._gamma_host_stale = False
         self._gamma_on_device = False
+        self._gamma_init_pending = False
 
     def __getstate__(self):
         """Snapshots are pickles of the whole object (launch_train.py:203-204):
@@ -133,9 +139,8 @@ class VariationalBayes(Inferencer):
         self._parsed_corpus = None
         self._train_csr = self.parse_to_csr(corpus)
         self._number_of_documents = len(self._train_csr[0]) - 1
-        self._gamma = (numpy.zeros((self._number_of_documents, self._number_of_topics))
-                       + self._alpha_alpha[numpy.newaxis, :]
-                       + 1.0 * self._number_of_types / self._number_of_topics)          # :92
+        self._gamma = None
+        self._gamma_init_pending = True      # :92's value, materialised when first read
         self._eta = numpy.random.gamma(100., 1. / 100.,
                                        (self._number_of_topics, self._number_of_types))  # :95
         self._ctx = None
@@ -156,6 +161,7 @@ class VariationalBayes(Inferencer):
         self._train_csr = (numpy.asarray(doc_ptr), numpy.asarray(term_id), numpy.asarray(term_ct))
         self._number_of_documents = len(doc_ptr) - 1
         self._gamma = None
+        self._gamma_init_pending = True      # :92's value, materialised when first read
         if eta is None:
             eta = numpy.random.gamma(100., 1. / 100., (self._number_of_topics, self._number_of_types))
         self._eta = eta
@@ -221,10 +227,15 @@ class VariationalBayes(Inferencer):
         phi_sufficient_statistics = numpy.asarray(phi_sufficient_statistics, dtype=numpy.float64)
         assert phi_sufficient_statistics.shape == (self._number_of_topics, self._number_of_types)
         ctx.set_sstats(phi_sufficient_statistics)
-        corpus = self._training_corpus()
-        if not self._gamma_on_device:
-            raise RuntimeError("m_step needs the gamma of a training e_step() on this object")
-        topic_log_likelihood, alpha_sufficient_statistics = ctx.mstep(corpus, self._alpha_beta)
+        if self._gamma_on_device:
+            topic_log_likelihood, alpha_sufficient_statistics = ctx.mstep(self._training_corpus(),
+                                                                          self._alpha_beta)
+        else:
+            # self._gamma was assigned by the caller (or comes from _initialize / a snapshot): the
+            # K-vector of :232-233 from that host array, as the reference does
+            topic_log_likelihood, _ = ctx.mstep(None, self._alpha_beta, want_alpha_ss=False)
+            alpha_sufficient_statistics = numpy.sum(
+                compute_dirichlet_expectation(numpy.asarray(self._gamma, dtype=numpy.float64)), axis=0)
         self._eta_device_newer = True
         self._eta_host_newer = False
         return topic_log_likelihood, alpha_sufficient_statistics

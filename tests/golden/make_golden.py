@@ -16,6 +16,8 @@ not depend on the hash seed.)
 
 Fixtures
   tiny_k2.npz        D=3, V=7, K=2 hand-checkable corpus, training + held-out
+  tiny_exports.npz   the bytes export_beta / export_gamma write for that corpus after two
+                     learning() iterations (full and top_display=2), with the eta / gamma they came from
   ap_train_k10.npz   AP train split (2000 docs) K=10: state after 2 learning()
                      iterations, then per-document goldens of the 3rd e_step,
                      the m_step outputs and the alpha Newton update
@@ -134,6 +136,31 @@ def make_tiny(vb):
         gamma_corpus=gamma_corpus, heldout_gamma=hgamma, heldout_words_ll=hwll,
         heldout_iters=hiters, heldout_corpus_words_ll=wll, heldout_corpus_gamma=hg)
     print("tiny_k2: corpus_ll=%r words_ll=%r iters=%s" % (ll, wll, iters))
+
+
+def make_tiny_exports(vb):
+    """The reference's export_beta / export_gamma text (variational_bayes.py:326-356) on the tiny
+    case, full and with top_display=2: the model state it was written from and the exact bytes."""
+    import tempfile
+    docs = ["a b b c", "c c d e e e f", "g a a g b"]
+    vocab = ["a", "b", "c", "d", "e", "f", "g"]
+    np.random.seed(7)
+    m = vb.VariationalBayes()
+    quiet(m._initialize, docs, vocab, 2, 0.5, 0.1)
+    quiet(m.learning)
+    quiet(m.learning)
+    words = [m._index_to_type[i] for i in range(len(vocab))]
+    texts = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, fn, top in (("exp_beta", m.export_beta, -1), ("exp_beta_top2", m.export_beta, 2),
+                              ("exp_gamma", m.export_gamma, -1), ("exp_gamma_top2", m.export_gamma, 2)):
+            path = os.path.join(tmp, name)
+            fn(path, top)
+            with open(path, "rb") as fh:
+                texts[name] = np.frombuffer(fh.read(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "tiny_exports.npz"), words=np.array(words), eta=m._eta.copy(),
+                        gamma=m._gamma.copy(), **texts)
+    print("tiny_exports: %s" % {k: v.size for k, v in texts.items()})
 
 
 def make_ap(vb, trace_iters):
@@ -288,7 +315,7 @@ def make_special():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--trace", type=int, default=3, help="AP K=10 trace length (iterations)")
-    ap.add_argument("--only", default="", help="comma list of: tiny,ap,special,nips,nipstrace")
+    ap.add_argument("--only", default="", help="comma list of: tiny,exports,ap,special,nips,nipstrace")
     ap.add_argument("--nips-iterations", type=int, default=50)
     ap.add_argument("--nips-trace-out", default=None, help="write the nips trace here instead of over the committed fixture")
     args = ap.parse_args()
@@ -298,6 +325,8 @@ if __name__ == "__main__":
         make_special()
     if not only or "tiny" in only:
         make_tiny(vb)
+    if not only or "exports" in only:
+        make_tiny_exports(vb)
     if not only or "ap" in only:
         make_ap(vb, args.trace)
     if not only or "nips" in only:

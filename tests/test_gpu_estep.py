@@ -40,6 +40,9 @@ def run(capi, alpha, eta, ptr, tid, tct, heldout=False, max_iter=50, tol=1e-6, o
 
 def check_against(out, ref_gamma, ref_ll, ref_iters, ll_key="doc_ll", min_same=0.995):
     same = out["iters"] == ref_iters
+    # drift stays visible in the log (pytest -s / failure report): how many documents sit on the threshold
+    print("inner-iteration counts: %d of %d documents differ from the reference (allowed %.1f %%)"
+          % ((~same).sum(), same.size, 100.0 * (1.0 - min_same)))
     assert np.mean(same) >= min_same, "inner-iteration counts differ on %d documents" % (~same).sum()
     assert rel_err(out["gamma"][same], ref_gamma[same]) < GAMMA_RTOL
     assert np.all(np.abs(out[ll_key][same] - ref_ll[same]) <= LL_RTOL * np.abs(ref_ll[same]) + LL_ATOL)
@@ -108,7 +111,7 @@ def test_ap_heldout_k10_matches_reference_goldens(capi, ap_test):
     assert abs(out["words_log_likelihood"] - float(g["corpus_words_ll"])) < 1e-9 * abs(float(g["corpus_words_ll"]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6, 7, 8, 9])
 def test_every_kernel_variant_agrees(capi, ap_train, variant):
     g = ap_train
     docs = list(range(0, 2000, 10))
@@ -210,7 +213,7 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
     ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
     gen = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 1)])
     held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
-    for variant in (4, 5, 6, 7, 8, 9):           # slab, column, quilt (register tiles), streaming, hybrid, wide tiered
+    for variant in (4, 6, 7, 8, 9):              # slab, quilt (register tiles), streaming, hybrid, wide tiered
         out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
         check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
         assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
@@ -225,7 +228,7 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 3, 4, 6, 7, 8, 9])
 def test_training_fast_path_corpus_likelihood(capi, ap_train, variant):
     """Option doc_values=0 (what learning() uses): the corpus-level document_log_likelihood must equal
     the sum of the complete per-document values, and the reference's own corpus value."""
@@ -295,7 +298,9 @@ def test_iteration_cap_and_threshold_on_register_kernels(capi, K, V, mean_len):
     ptr, ids, cts = random_corpus(rng, 24, V, mean_len)
     eta = rng.gamma(100.0, 0.01, (K, V))
     alpha = rng.uniform(0.05, 1.0, K)
-    for mi, tol in [(1, 1e-6), (2, 1e-6), (50, 1e-1), (7, 0.0), (5, -1.0), (50, 1e-3)]:
+    # (7, 0.0), (5, -1.0), (9, 1e-13), (50, 2000.0): outside the fixed-point stop test's range - the library
+    # routes those E-steps to the kernels that compare in floating point (capi.hip choose_variant)
+    for mi, tol in [(1, 1e-6), (2, 1e-6), (50, 1e-1), (7, 0.0), (5, -1.0), (50, 1e-3), (9, 1e-13), (50, 2000.0)]:
         ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
         out = run(capi, alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
         assert np.array_equal(out["iters"], ref["iters"]), (mi, tol)

@@ -1,5 +1,5 @@
-"""Parity at BASELINE.json's FULL sizes through size-independent properties (the oracle cannot
-finish 100k documents): conservation laws of the algorithm, fast-path / per-document agreement,
+"""Parity at BASELINE.json's FULL sizes (cfg 3: 100k documents K=128, cfg 4: 1M documents K=256)
+through size-independent properties (the oracle cannot finish 100k documents): conservation laws of the algorithm, fast-path / per-document agreement,
 shard-additivity of the sufficient statistics, bitwise reproducibility, and an oracle spot check
 on documents drawn from the full-size run."""
 import numpy as np
@@ -10,14 +10,24 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def cfg3():
-    """cfg 3: synthetic LDA corpus, 100,000 documents, V=50,000, K=128 (bench.py's default workload)."""
-    import torch
+CONFIGS = {
+    # name: (bench workload, documents, V, K, seed)
+    "cfg3": ("synth100k", 100000, 50000, 128, 1234),      # bench.py's primary workload
+    "cfg4": ("synth1m", 1000000, 100000, 256, 5678),      # BASELINE.json configs[3] at its full size on one GPU
+}
+
+
+@pytest.fixture(scope="module", params=["cfg3", "cfg4"])
+def cfg3(request):
+    """cfg 3: synthetic LDA corpus, 100,000 documents, V=50,000, K=128 (quilt kernels);
+    cfg 4: 1,000,000 documents, V=100,000, K=256 (wide tiered kernels, incl. the multi-round class for the
+    29 documents with more than 256 distinct terms).  Same generator, seeds and sizes as bench.py."""
+    import bench
     from pylda_amd import _capi
-    from pylda_amd.corpus import synthetic_lda_corpus_torch
-    ptr, ids, cts = synthetic_lda_corpus_torch(100000, 50000, 128, 200, 1234, device="cuda", chunk=25000)
-    K, V = 128, 50000
+    from pylda_amd.corpus import corpus_checksum, synthetic_lda_shard
+    workload, D, V, K, seed = CONFIGS[request.param]
+    ptr, ids, cts = synthetic_lda_shard(D, V, 0, D, 128, 200, seed, chunk=25000, device="cuda", workers=8)
+    assert corpus_checksum(ptr, ids, cts) == bench.EXPECTED_CHECKSUM[workload]     # the corpus bench.py times
     np.random.seed(0)
     eta = np.random.gamma(100., 1. / 100., (K, V))
     alpha = np.full(K, 1.0 / K)
@@ -28,9 +38,10 @@ def cfg3():
     ctx.set_option("doc_values", 1)
     ctx.estep(corpus)
     ll, _, nlog = ctx.estep_results(corpus)
-    out = dict(ctx=ctx, corpus=corpus, ptr=ptr, ids=ids, cts=cts, K=K, V=V, eta=eta, alpha=alpha, ll=ll,
-               nlog=nlog, gamma=ctx.get_gamma(corpus), sstats=ctx.get_sstats())
+    out = dict(name=request.param, ctx=ctx, corpus=corpus, ptr=ptr, ids=ids, cts=cts, K=K, V=V, D=D, eta=eta,
+               alpha=alpha, ll=ll, nlog=nlog, gamma=ctx.get_gamma(corpus), sstats=ctx.get_sstats())
     out["doc_ll"], _, out["iters"] = ctx.get_doc_values(corpus)
+    print("%s: launch classes %s" % (request.param, [(c["kernel"], c["geometry"], c["documents"]) for c in corpus.plan()]))
     yield out
     corpus.close()
     ctx.close()
@@ -90,9 +101,13 @@ def test_oracle_spot_check_on_full_size_run(cfg3):
     from oracle import c_oracle
     c = cfg3
     rng = np.random.default_rng(0)
-    docs = np.sort(rng.choice(100000, 24, replace=False))
+    docs = np.sort(rng.choice(c["D"], 24, replace=False))
     order = np.argsort(np.diff(c["ptr"]))
     docs = np.unique(np.concatenate([docs, order[:2], order[-2:]]))      # plus the shortest and longest
+    if c["name"] == "cfg4":             # the longest have > 256 distinct terms: the wide kernel's multi-round class
+        assert np.diff(c["ptr"])[order[-1]] > 256
+        kernels = {(p["kernel"], p["geometry"]) for p in c["corpus"].plan()}
+        assert ("qwide", 1) in kernels and ("qwide", 2) in kernels, kernels
     from conftest import csr_slice
     ptr, tid, tct = csr_slice(c["ptr"], c["ids"], c["cts"], docs)
     ref = c_oracle.e_step(c["alpha"], c["eta"], ptr, tid, tct)

@@ -203,3 +203,56 @@ def test_nips_k500_trace_and_heldout_likelihood():
     assert rel_err(m._alpha_alpha, g["alpha_last"]) < 1e-6
     print("nips K=500: %d iterations match; held-out per-token log-likelihood %.6f"
           % (n_iter, (heldout[max(heldout)] / int(g["test_tokens"])) if heldout else float("nan")))
+
+
+def test_tiny_exports_end_to_end_match_reference_bytes(tiny, tmp_path):
+    """text -> _initialize (seed 7, the reference's eta draw) -> two learning() iterations on the
+    GPU -> export_beta / export_gamma: the files equal, byte for byte, what the reference wrote after the
+    same calls (tests/golden/make_golden.py::make_tiny_exports; `%g` keeps six significant digits)."""
+    from pylda_amd.variational_bayes import VariationalBayes
+    g = load_golden("tiny_exports.npz")
+    np.random.seed(7)
+    m = VariationalBayes()
+    m._verbose = False
+    m._initialize([str(d) for d in tiny["docs"]], [str(w) for w in g["words"]], 2, 0.5, 0.1)
+    export_before = tmp_path / "before"
+    m.export_gamma(str(export_before))                  # usable before the first learning() (:92's gamma)
+    assert len(export_before.read_text().splitlines()) == 3
+    m.learning()
+    m.learning()
+    assert rel_err(m._eta, g["eta"]) < 1e-10 and rel_err(m._gamma, g["gamma"]) < 1e-10
+    for name, fn, top in (("exp_beta", m.export_beta, -1), ("exp_beta_top2", m.export_beta, 2),
+                          ("exp_gamma", m.export_gamma, -1), ("exp_gamma_top2", m.export_gamma, 2)):
+        path = tmp_path / name
+        fn(str(path), top)
+        assert path.read_bytes() == bytes(g[name]), name
+
+
+def test_m_step_uses_a_host_gamma_the_caller_assigned(ap_train):
+    """m_step reads self._gamma (:232-233) - also when the caller assigned it, or it comes from
+    _initialize / a snapshot, instead of from the last training e_step() on the device."""
+    from oracle import vb_numpy
+    from pylda_amd.variational_bayes import VariationalBayes
+    g = ap_train
+    ptr = g["doc_ptr"][:201]
+    m = VariationalBayes()
+    m._verbose = False
+    m._initialize_parsed(ptr, g["term_id"][:ptr[-1]], g["term_ct"][:ptr[-1]], 6806, 10, 0.1, 1.0 / 6806,
+                         eta=g["eta"].copy())
+    sstats = np.random.default_rng(0).gamma(1.0, 1.0, (10, 6806))
+    # straight after initialisation: gamma is the constant matrix of :92
+    gamma0 = m._gamma.copy()
+    assert gamma0.shape == (200, 10) and np.allclose(gamma0, 0.1 + 6806 / 10.0)
+    tll, ass = m.m_step(sstats)
+    tll_ref, ass_ref, eta_ref = vb_numpy.m_step(g["eta"], m._alpha_beta, sstats, gamma0)
+    assert abs(tll - tll_ref) < 1e-10 * abs(tll_ref) and rel_err(ass, ass_ref) < 1e-12
+    assert rel_err(m._eta, eta_ref) < 1e-13
+    # a gamma the caller assigns
+    mine = np.random.default_rng(1).gamma(2.0, 1.0, (200, 10))
+    m._gamma = mine
+    _, ass = m.m_step(sstats)
+    assert rel_err(ass, vb_numpy.m_step(eta_ref, m._alpha_beta, sstats, mine)[1]) < 1e-12
+    # after a training e_step the device copy is the one in use again
+    m.e_step()
+    _, ass = m.m_step(sstats)
+    assert rel_err(ass, vb_numpy.m_step(eta_ref, m._alpha_beta, sstats, m._gamma)[1]) < 1e-10

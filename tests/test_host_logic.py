@@ -139,3 +139,66 @@ def test_native_ingest_matches_parse_data_rules(ap_train):
     assert t4.tolist() == [1, 0] and c4.tolist() == [2, 1]
     p5, t5, c5, d5 = _capi.parse_corpus([], ["a"])
     assert p5.tolist() == [0] and t5.size == 0 and d5 == 0
+
+
+def test_exports_match_reference_bytes(tmp_path):
+    """export_beta / export_gamma (variational_bayes.py:326-356) against the bytes the reference
+    itself wrote for the tiny corpus (tests/golden/make_golden.py::make_tiny_exports): header lines,
+    descending order, `%g` formatting, top_display cut."""
+    from pylda_amd.variational_bayes import VariationalBayes
+    g = load_golden("tiny_exports.npz")
+    m = VariationalBayes()
+    m._verbose = False
+    m.parse_vocabulary([str(w) for w in g["words"]])
+    m._number_of_topics, m._number_of_documents = g["eta"].shape[0], g["gamma"].shape[0]
+    m._eta = g["eta"].copy()
+    m._gamma = g["gamma"].copy()
+    for name, fn, top in (("exp_beta", m.export_beta, -1), ("exp_beta_top2", m.export_beta, 2),
+                          ("exp_gamma", m.export_gamma, -1), ("exp_gamma_top2", m.export_gamma, 2)):
+        path = tmp_path / name
+        fn(str(path), top)
+        assert path.read_bytes() == bytes(g[name]), name
+
+
+def test_native_ingest_python_whitespace_and_awkward_vocabulary():
+    """The tokeniser splits exactly where str.split() does (Unicode white space, control separators), a
+    document that contains line breaks stays one document, and vocabulary entries no token can match
+    (empty, containing or surrounded by white space) keep their ids without shifting the others."""
+    from pylda_amd import _capi
+    vocab = ["a", "", "b c", "d", " e", "f ", "g", "　", "h\x00i", "été"]
+    index = {w: i for i, w in enumerate(vocab)}
+    lines = ["a d g\x1cg\x85a", "d\ng\r\na", "a b c d", "　  ", "e f g", "g\x00a", "h\x00i g\x01",
+             "a\x0bd\x0cg\x1d\x1e\x1fg", " a  d ", "été a d g g a d g",
+             "a​d"]                                   # U+200B is NOT white space for str.split()
+    ptr, tid, tct, dropped = _capi.parse_corpus(lines, vocab)
+    ref_ids, ref_cts = reference_rules_parse(lines, index)
+    assert len(ref_ids) == 8                               # the test data exercises both kept and dropped lines
+    assert len(ptr) - 1 == len(ref_ids) and dropped == len(lines) - len(ref_ids)
+    for d, (ri, rc) in enumerate(zip(ref_ids, ref_cts)):
+        assert tid[ptr[d]:ptr[d + 1]].tolist() == ri and tct[ptr[d]:ptr[d + 1]].tolist() == rc
+    # the separator search falls through to 0xFF when every control candidate occurs in the text
+    hard = ["a\x00d", "g\x01a", "d\x02g", "a\x03g", "d"]
+    p2, t2, c2, _ = _capi.parse_corpus(hard, vocab)
+    r2, _ = reference_rules_parse(hard, index)
+    assert len(p2) - 1 == len(r2) and [t2[p2[d]:p2[d + 1]].tolist() for d in range(len(r2))] == r2
+
+
+def test_bench_launcher_command_line():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run."""
+    import bench
+    argv = bench.launcher_argv(4, ["--gpus", "4", "--steps", "7"])
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert argv[argv.index("--nproc-per-node") + 1] == "4" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[-5].endswith("bench.py") and argv[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert bench.algorithmic_bytes(10, 2, 4) == 10 * (8 + 64) + 2 * (32 + 8)
+
+
+def test_hybrid_corpus_generator_is_the_numpy_generator():
+    """The generator bench.py uses (numpy PCG64 draws, collapse on a torch device, chunks drawn ahead by
+    threads) gives the all-numpy corpus bit for bit; shards are slices of the whole."""
+    a = C.synthetic_lda_shard(900, 300, 0, 900, 7, 40, seed=11, chunk=300)
+    b = C.synthetic_lda_shard(900, 300, 0, 900, 7, 40, seed=11, chunk=300, device="cpu", workers=3)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    s = C.synthetic_lda_shard(900, 300, 300, 900, 7, 40, seed=11, chunk=300, device="cpu", workers=2)
+    assert np.array_equal(s[1], a[1][a[0][300]:]) and np.array_equal(s[0], a[0][300:] - a[0][300])
+    assert C.corpus_checksum(*a) == [900, int(a[0][-1]), int(a[1].astype(np.int64).sum()), int(a[2].sum())]
