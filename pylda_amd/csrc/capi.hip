@@ -22,6 +22,7 @@
 #include "estep_logspace.h"
 #include "estep_slab.h"
 #include "estep_quilt.h"
+#include "estep_quad.h"
 #include "estep_qstream.h"
 #include "estep_qhybrid.h"
 #include "estep_qwide.h"
@@ -45,7 +46,8 @@ enum Variant : int {
     kQuilt = 6,         // tile in registers, 4 x 16 word-group x topic lanes (estep_quilt.h)
     kQstream = 7,       // tile streamed from L2 twice per iteration, quilt lanes (estep_qstream.h)
     kQhybrid = 8,       // tile split over registers / LDS / streamed remainder (estep_qhybrid.h)
-    kQwide = 9          // the same three tiers on a 2 x 32 lane grid with prefetched tail rows (estep_qwide.h)
+    kQwide = 9,         // the same three tiers on a 2 x 32 lane grid with prefetched tail rows (estep_qwide.h)
+    kQuad = 10          // 4 wavefronts / document, two documents per CU, tile in registers + LDS rows (estep_quad.h)
 };
 
 struct Launch {
@@ -99,6 +101,8 @@ struct pylda_ctx {
     int force_variant = -1;
     int quilt12 = 0;
     int gather_rows = 1;            // whole-row gather kernel for ldk 64 / 128 / 256
+    int lds_pad = 0;                // A/B: extra dynamic LDS per quad workgroup (forces one workgroup per CU)
+    int quad = 1;                   // 4-wavefront documents, two per CU (K <= 128, N <= 208)
     int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
     int doc_values = 1;             // 1: per-document log-likelihoods complete (see EstepParams::want_doc_ll)
     int plan_epoch = 0;
@@ -226,6 +230,20 @@ QuiltGeom quilt_geom_for(const pylda_ctx* ctx, int n)
     if (n <= 256) return {8, 8};
     return {0, 0};
 }
+// Quad kernel (4 wavefronts per document, two documents per CU): register slots and LDS slots per
+// word group, N <= 16 * (RWL + TWL); code RWL * 100 + TWL, or 0.  TWL <= 3 keeps two workgroups inside
+// a CU's 160 KiB of LDS; longer documents go to the 8-wavefront quilt kernel.
+int quad_geom_for(const pylda_ctx* ctx, int n)
+{
+    if (ctx->ldk != 128 || !ctx->quad) return 0;
+    if (n <= 128) return 800;
+    if (n <= 160) return 1000;
+    if (n <= 176) return 1001;
+    if (n <= 192) return 1002;
+    if (n <= 208) return 1003;
+    return 0;
+}
+
 int quilt_rwl_for(const pylda_ctx* ctx, int n) { const QuiltGeom q = quilt_geom_for(ctx, n); return q.W * 100 + q.RWL; }
 
 // Hybrid kernel: 128 < K <= 256 (ldk 192 / 256), or long documents at ldk 64 / 128.
@@ -256,6 +274,10 @@ int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
     // Outside that range (threshold 0: "run until nothing moves at all"; huge thresholds) the
     // generic kernels, which compare in floating point, take the documents.
     if (ctx->exact_stop) goto generic;
+    if ((ctx->force_variant < 0 || ctx->force_variant == kQuad) && quad_geom_for(ctx, n) > 0) {
+        *lds_bytes = 0;
+        return kQuad;
+    }
     if ((ctx->force_variant < 0 || ctx->force_variant == kQuilt) && quilt_geom_for(ctx, n).W > 0) {
         *lds_bytes = 0;
         return kQuilt;
@@ -319,6 +341,7 @@ void build_plan(pylda_corpus* c)
             const int vj = choose_variant(ctx, c->h_terms_sorted[j], &lds_j);
             if (vj != v) break;
             if (v == kQuilt && quilt_rwl_for(ctx, c->h_terms_sorted[j]) != quilt_rwl_for(ctx, c->h_terms_sorted[i])) break;
+            if (v == kQuad && quad_geom_for(ctx, c->h_terms_sorted[j]) != quad_geom_for(ctx, c->h_terms_sorted[i])) break;
             if (v == kQwide && qwide_rounds_for(c->h_terms_sorted[j]) != qwide_rounds_for(c->h_terms_sorted[i])) break;
             if (v == kSlab) {
                 const SlabGeom gi = slab_geom_for(ctx, c->h_terms_sorted[i]), gj = slab_geom_for(ctx, c->h_terms_sorted[j]);
@@ -338,6 +361,7 @@ void build_plan(pylda_corpus* c)
         L.lds_bytes = lds_first;
         L.rn = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RN
              : v == kQuilt ? quilt_rwl_for(ctx, c->h_terms_sorted[i])
+             : v == kQuad ? quad_geom_for(ctx, c->h_terms_sorted[i])
              : v == kQwide ? qwide_rounds_for(c->h_terms_sorted[i]) : 0;
         L.rk = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RK : 0;
         c->plan.push_back(L);
@@ -410,6 +434,31 @@ int launch_quilt_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     QUILT_CASE(12, 4, 4) QUILT_CASE(12, 8, 4)
 #undef QUILT_CASE
     return fail(ctx, PYLDA_ERR_STATE, "no quilt kernel for KRL=%d RWL=%d", KRL, L.rn);
+}
+
+template <int KRL, int RWL, int TWL>
+int launch_quad(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    auto kern = estep_quad_kernel<KRL, RWL, TWL>;
+    const size_t lds = QuadLds<KRL, RWL, TWL>::total + (size_t)ctx->lds_pad;
+    if (lds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * kQuadWaves), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    switch (L.rn) {
+    case 800: return launch_quad<8, 8, 0>(ctx, p, L);
+    case 1000: return launch_quad<8, 10, 0>(ctx, p, L);
+    case 1001: return launch_quad<8, 10, 1>(ctx, p, L);
+    case 1002: return launch_quad<8, 10, 2>(ctx, p, L);
+    case 1003: return launch_quad<8, 10, 3>(ctx, p, L);
+    }
+    return fail(ctx, PYLDA_ERR_STATE, "no quad kernel for geometry %d", L.rn);
 }
 
 template <int KRL>
@@ -774,7 +823,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kQwide || value == kRetired5)
+        if (value < -1 || value > kQuad || value == kRetired5)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld is not a kernel variant", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
@@ -782,6 +831,11 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         ctx->gather_rows = value != 0;
     } else if (!strcmp(name, "quilt_odd")) {
         ctx->quilt_odd = value != 0;
+        ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "lds_pad")) {
+        ctx->lds_pad = (int)value;
+    } else if (!strcmp(name, "quad")) {
+        ctx->quad = value != 0;
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "quilt12")) {
         ctx->quilt12 = value != 0;
@@ -1062,6 +1116,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kQstream: rc = launch_qstream_any(ctx, p, L); break;
             case kQhybrid: rc = launch_qhybrid_any(ctx, p, L); break;
             case kQwide: rc = launch_qwide_any(ctx, p, L); break;
+            case kQuad: rc = launch_quad_any(ctx, p, L); break;
             default: rc = launch_generic<256, true>(ctx, p, L); break;
             }
             close_bracket(class_bracket, ctx->stream);

@@ -111,7 +111,7 @@ def test_ap_heldout_k10_matches_reference_goldens(capi, ap_test):
     assert abs(out["words_log_likelihood"] - float(g["corpus_words_ll"])) < 1e-9 * abs(float(g["corpus_words_ll"]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10])
 def test_every_kernel_variant_agrees(capi, ap_train, variant):
     g = ap_train
     docs = list(range(0, 2000, 10))
@@ -200,7 +200,7 @@ def test_random_corpora_against_c_oracle(capi, K, V, D, mean_len):
 
 @pytest.mark.parametrize("K,V,mean_len", [(10, 300, 20), (16, 300, 150), (17, 400, 90), (32, 500, 260),
                                           (50, 600, 120), (64, 700, 330), (100, 900, 200), (128, 900, 150),
-                                          (128, 1200, 230), (128, 1200, 40)])
+                                          (128, 1200, 230), (128, 1200, 40), (128, 1500, 185), (110, 1500, 200)])
 def test_register_resident_slab_kernels(capi, K, V, mean_len):
     """The slab kernels (tile in VGPRs) over every (wavefronts, slab width, words per lane) geometry,
     against the C oracle and against the generic LDS kernel."""
@@ -213,7 +213,7 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
     ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
     gen = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 1)])
     held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
-    for variant in (4, 6, 7, 8, 9):              # slab, quilt (register tiles), streaming, hybrid, wide tiered
+    for variant in (4, 6, 7, 8, 9, 10):          # slab, quilt (register tiles), streaming, hybrid, wide tiered, quad
         out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
         check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
         assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
@@ -228,7 +228,7 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 3, 4, 6, 7, 8, 9, 10])
 def test_training_fast_path_corpus_likelihood(capi, ap_train, variant):
     """Option doc_values=0 (what learning() uses): the corpus-level document_log_likelihood must equal
     the sum of the complete per-document values, and the reference's own corpus value."""
