@@ -267,6 +267,76 @@ __device__ __forceinline__ void row_bcast_matvec(double (&q)[KRL], double r, con
     }
 }
 
+// ---- hand-ordered FMA blocks -------------------------------------------------------------------
+// hipcc schedules these kernels for register pressure (they sit at the 256-VGPR limit) and then
+// interleaves only TWO accumulator chains; a lone wavefront issues a 2-chain fp64 stream at 6.4
+// ticks per instruction against 4.9 for 8 chains (tools/valu_bench.hip).  An asm statement is
+// scheduled as a unit, so the blocks below fix the order: eight independent chains per block.
+
+// a[i] = b_i * t  /  a[i] += b_i * t   for the eight words a lane holds at one topic
+__device__ __forceinline__ void col_mul8(double (&a)[8], double b0, double b1, double b2, double b3, double b4, double b5,
+                                         double b6, double b7, double t)
+{
+    asm("v_mul_f64 %0, %8, %16\n\tv_mul_f64 %1, %9, %16\n\tv_mul_f64 %2, %10, %16\n\tv_mul_f64 %3, %11, %16\n\t"
+        "v_mul_f64 %4, %12, %16\n\tv_mul_f64 %5, %13, %16\n\tv_mul_f64 %6, %14, %16\n\tv_mul_f64 %7, %15, %16"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+        : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5), "v"(b6), "v"(b7), "v"(t));
+}
+__device__ __forceinline__ void col_fmac8(double (&a)[8], double b0, double b1, double b2, double b3, double b4, double b5,
+                                          double b6, double b7, double t)
+{
+    asm("v_fmac_f64_e32 %0, %8, %16\n\tv_fmac_f64_e32 %1, %9, %16\n\tv_fmac_f64_e32 %2, %10, %16\n\t"
+        "v_fmac_f64_e32 %3, %11, %16\n\tv_fmac_f64_e32 %4, %12, %16\n\tv_fmac_f64_e32 %5, %13, %16\n\t"
+        "v_fmac_f64_e32 %6, %14, %16\n\tv_fmac_f64_e32 %7, %15, %16"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+        : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(b4), "v"(b5), "v"(b6), "v"(b7), "v"(t));
+}
+
+// sum_j row[j] * t[j] over a lane's eight topics of ONE word: four chains of two, then a tree
+__device__ __forceinline__ double dot8(const double (&row)[8], const double (&t)[8])
+{
+    double p0, p1, p2, p3;
+    asm("v_mul_f64 %0, %4, %12\n\tv_mul_f64 %1, %6, %14\n\tv_mul_f64 %2, %8, %16\n\tv_mul_f64 %3, %10, %18\n\t"
+        "v_fmac_f64_e32 %0, %5, %13\n\tv_fmac_f64_e32 %1, %7, %15\n\tv_fmac_f64_e32 %2, %9, %17\n\tv_fmac_f64_e32 %3, %11, %19\n\t"
+        "v_add_f64 %0, %0, %1\n\tv_add_f64 %2, %2, %3\n\tv_add_f64 %0, %0, %2"
+        : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+        : "v"(row[0]), "v"(row[1]), "v"(row[2]), "v"(row[3]), "v"(row[4]), "v"(row[5]), "v"(row[6]), "v"(row[7]),
+          "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]));
+    return p0;
+}
+
+// An LDS row (a lane's eight topics of one word: four 16-byte pieces, 256 bytes apart) requested NOW
+// and waited for LATER: the compiler would sink the reads to their first use (register pressure) and
+// serialise the round trips.  lds_row_request issues the four ds_read_b128; the values may only be
+// used after lds_row_wait, which hands them over as its outputs.  (A wavefront's LDS operations return
+// in order, so the compiler's own lgkmcnt waits stay sufficient with these extra reads in flight.)
+struct LdsRow {
+    f64x2 p[4];
+    // valid after lds_row_wait only
+    __device__ __forceinline__ void unpack(double (&row)[8]) const
+    {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            row[2 * jj] = p[jj].x;
+            row[2 * jj + 1] = p[jj].y;
+        }
+    }
+};
+__device__ __forceinline__ void lds_row_request(LdsRow& r, const void* lds_ptr)
+{
+    typedef __attribute__((address_space(3))) const char* lds_cptr;
+    const unsigned addr = (unsigned)(uintptr_t)(lds_cptr)lds_ptr;      // LDS byte offset
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:256\n\tds_read_b128 %2, %4 offset:512\n\t"
+                 "ds_read_b128 %3, %4 offset:768"
+                 : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
+                 : "v"(addr)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_row_wait(LdsRow& r)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
+}
+
 // sum over aligned groups of LPW (1, 2, 4 or 8) neighbouring lanes; every lane of a group gets it
 template <int LPW>
 __device__ __forceinline__ double lane_group_sum(double s)

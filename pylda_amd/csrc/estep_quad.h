@@ -42,7 +42,11 @@ struct QuadLds {
     static constexpr size_t tt = sp + (size_t)W * kTopics * 8;                     // [2][kTopics]
     static constexpr size_t chg = tt + (size_t)2 * kTopics * 8;                    // u64[2]
     static constexpr size_t misc = chg + 16;                                       // [8][W]
-    static constexpr size_t rows = (misc + (size_t)8 * W * 8 + 255) & ~(size_t)255;   // [16][TWL][kTopics]
+    static constexpr size_t alf = misc + (size_t)8 * W * 8;                        // [kTopics] alpha (0 beyond K)
+    static constexpr size_t gpv = alf + (size_t)kTopics * 8;                       // [kTopics] gamma before the last update
+    static constexpr size_t cnt = gpv + (size_t)kTopics * 8;                       // int32 [2][W * 64] counts of the words a lane finishes
+    static constexpr size_t rows = (cnt + (size_t)2 * W * 64 * 4 + 255) & ~(size_t)255;   // [16][TWL][kTopics]
+    static_assert(TWL < 3 || 2 * ((cnt + (size_t)2 * W * 64 * 4 + 255) / 256 * 256 + (size_t)16 * TWL * kTopics * 8) <= 160 * 1024, "two workgroups per CU");
     static constexpr size_t total = rows + (size_t)16 * TWL * kTopics * 8;
 };
 
@@ -69,6 +73,10 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
     double* tt = reinterpret_cast<double*>(smem + L::tt);
     unsigned long long* chg = reinterpret_cast<unsigned long long*>(smem + L::chg);
     double* misc = reinterpret_cast<double*>(smem + L::misc);
+    // per-thread constants of the inner loop live in LDS, not in VGPRs (the tile takes 160 of 256):
+    double* alf = reinterpret_cast<double*>(smem + L::alf);
+    double* gpv = reinterpret_cast<double*>(smem + L::gpv);
+    int* cntv = reinterpret_cast<int*>(smem + L::cnt);
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -93,15 +101,15 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
     const int word0 = slot0 * 16 + gg, word1 = slot1 * 16 + gg;
     const bool live0 = slot0 < C0 && word0 < N;
     const bool live1 = C1 > 0 && slot1 < WPG && word1 < N;
-    const double cnt0 = live0 ? (double)p.term_ct[lo + word0] : 0.0;
-    const double cnt1 = live1 ? (double)p.term_ct[lo + word1] : 0.0;
+    cntv[tid] = live0 ? p.term_ct[lo + word0] : 0;
+    cntv[NT + tid] = live1 ? p.term_ct[lo + word1] : 0;
     double local = 0.0;
     for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
     double asum = 0.0;
     for (int k = lane; k < K; k += kWave) asum += p.alpha[k];
     const bool topic_thread = tid < KT;
     const bool topic_live = tid < K;
-    const double alpha_k = topic_live ? p.alpha[tid] : 1.0;
+    if (topic_thread) alf[tid] = topic_live ? p.alpha[tid] : 1.0;
 
     // ---- the tile gather: register slots, then the LDS slots (through registers) ----
     double B[RWL][KRL];
@@ -147,16 +155,14 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
     const double psi_total = uniform_f64(digamma(asum + total));
 
     // ---- gamma phase state: thread k < KT owns topic k ----
-    double gam = topic_live ? alpha_k + total / K : alpha_k;              // :165 (padding topics never move)
-    double gam_prev = gam;
-    double t_mine = 0.0;
+    double gam = 1.0;
     if (topic_thread) {
-        t_mine = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
-        tt[tid] = t_mine;
+        gam = topic_live ? alf[tid] + total / K : 1.0;                    // :165 (padding topics never move)
+        tt[tid] = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
     }
     lds_only_barrier();
 
-    double r0 = 0.0, r1 = 0.0, nrm0 = 1.0, nrm1 = 1.0;
+    double r0 = 0.0, r1 = 0.0;
     int it = 0;
     int bad = 0;
     double* myred = red + (size_t)wave * 4 * 8 * RS + (size_t)g * 8 * RS;         // this lane group's 8 rows
@@ -178,90 +184,123 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
 #pragma unroll
     for (int j = 0; j < KRL; ++j) asm volatile("" : "+v"(tq[j]));
     ExpDigammaScalarCoef coef;
+    // The loop body is ordered by hand (estep_common.h, "hand-ordered FMA blocks"): FMA blocks of eight
+    // independent chains, and every LDS row requested one block of >= 16 FMAs before it is used, through
+    // ONE 16-VGPR row buffer:   [32 FMAs] row 0 [32 FMAs] row 1 [16 FMAs] row 2   in both passes.
+    LdsRow rowbuf;
+    auto request_row = [&](int t) { lds_row_request(rowbuf, myrows + t * (KT / 2)); };
+    if constexpr (TWL > 0) request_row(0);
     for (;;) {                                                            // :174
         const int buf = it & 1;
 
         // A. partial normalisers over this lane's topics -> LDS transpose -> sum over the 16 topic lanes
+        double a[8];
+        double pr[TWL > 0 ? TWL : 1];
+        auto row_partial = [&](auto idx) {                   // LDS slot t: partial normaliser, next row requested
+            constexpr int t = decltype(idx)::value;
+            if constexpr (t < TWL) {
+                lds_row_wait(rowbuf);
+                double row[8];
+                rowbuf.unpack(row);
+                pr[t] = dot8(row, tq);
+                if constexpr (t + 1 < TWL) request_row(t + 1);
+            }
+        };
+        static_assert(C0 == 8 || TWL == 0, "LDS slots need the eight-slot first chunk");
+        if constexpr (C0 == 8) {
+            col_mul8(a, B[0][0], B[1][0], B[2][0], B[3][0], B[4][0], B[5][0], B[6][0], B[7][0], tq[0]);
+            col_fmac8(a, B[0][1], B[1][1], B[2][1], B[3][1], B[4][1], B[5][1], B[6][1], B[7][1], tq[1]);
+            col_fmac8(a, B[0][2], B[1][2], B[2][2], B[3][2], B[4][2], B[5][2], B[6][2], B[7][2], tq[2]);
+            col_fmac8(a, B[0][3], B[1][3], B[2][3], B[3][3], B[4][3], B[5][3], B[6][3], B[7][3], tq[3]);
+            row_partial(StaticIndex<0>());
+            col_fmac8(a, B[0][4], B[1][4], B[2][4], B[3][4], B[4][4], B[5][4], B[6][4], B[7][4], tq[4]);
+            col_fmac8(a, B[0][5], B[1][5], B[2][5], B[3][5], B[4][5], B[5][5], B[6][5], B[7][5], tq[5]);
+            col_fmac8(a, B[0][6], B[1][6], B[2][6], B[3][6], B[4][6], B[5][6], B[6][6], B[7][6], tq[6]);
+            col_fmac8(a, B[0][7], B[1][7], B[2][7], B[3][7], B[4][7], B[5][7], B[6][7], B[7][7], tq[7]);
+            row_partial(StaticIndex<1>());
+        } else {
 #pragma unroll
-        for (int i = 0; i < C0; ++i) {
-            double a0 = B[i][0] * tq[0];
-#pragma unroll
-            for (int j = 1; j < KRL; ++j) a0 = fma(B[i][j], tq[j], a0);
-            myred[i * RS + c] = a0;
+            for (int i = 0; i < C0; ++i) a[i] = dot8(B[i], tq);
         }
-        if (moved <= thresh || left <= 0) break;                          // :189 (mean <= tol), :174
+#pragma unroll
+        for (int i = 0; i < C0; ++i) myred[i * RS + c] = a[i];
+        if (moved <= thresh || left <= 0) {                               // :189 (mean <= tol), :174
+            if constexpr (TWL > 2) lds_row_wait(rowbuf);                  // no read may land after the loop
+            break;
+        }
         wave_lds_exchange();
         double2 h0[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) h0[x] = mysrc[2 * x];                 // this lane's half of its word's 16 partials
-        double2 h1[4];
+        const double cnt0 = (double)cntv[tid];
+        double s0, s1 = 1.0, cnt1 = 0.0;
         if constexpr (C1 > 0) {
+            double a1[R1 > 0 ? R1 : 1];
+#pragma unroll
+            for (int i = 0; i < R1; ++i) a1[i] = dot8(B[8 + i], tq);
+            row_partial(StaticIndex<2>());
+            if constexpr (TWL > 0) request_row(0);                        // for pass B
+            s0 = ((h0[0].x + h0[1].x) + (h0[2].x + h0[3].x)) + ((h0[0].y + h0[1].y) + (h0[2].y + h0[3].y));
+            asm volatile("" : "+v"(s0));                                  // h0 is dead from here on
             wave_lds_exchange();                                          // the writes below stay behind the reads above
 #pragma unroll
-            for (int i = 0; i < R1; ++i) {
-                double a0 = B[8 + i][0] * tq[0];
+            for (int i = 0; i < R1; ++i) myred[i * RS + c] = a1[i];
 #pragma unroll
-                for (int j = 1; j < KRL; ++j) a0 = fma(B[8 + i][j], tq[j], a0);
-                myred[i * RS + c] = a0;
-            }
-#pragma unroll
-            for (int t = 0; t < TWL; ++t) {
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int jj = 0; jj < KRL / 2; ++jj) {
-                    const double2 b2 = myrows[t * (KT / 2) + 16 * jj];
-                    a0 = fma(b2.x, tq[2 * jj], a0);
-                    a1 = fma(b2.y, tq[2 * jj + 1], a1);
-                }
-                myred[(R1 + t) * RS + c] = a0 + a1;
-            }
+            for (int t = 0; t < TWL; ++t) myred[(R1 + t) * RS + c] = pr[t];
             wave_lds_exchange();
+            double2 h1[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) h1[x] = mysrc[2 * x];
-        }
-        {
-            const double sx = (h0[0].x + h0[1].x) + (h0[2].x + h0[3].x);
-            const double sy = (h0[0].y + h0[1].y) + (h0[2].y + h0[3].y);
-            const double s = lane_group_sum<2>(sx + sy);
-            nrm0 = s;
+            cnt1 = (double)cntv[NT + tid];
+            {   // the reciprocal chain of the first chunk runs while the second transpose is in flight
+                const double s = lane_group_sum<2>(s0);
+                if (live0 && !(s > 1e-280 && s < 1e300)) bad = 1;
+                r0 = live0 ? cnt0 * rcp_newton(s) : 0.0;
+            }
+            s1 = ((h1[0].x + h1[1].x) + (h1[2].x + h1[3].x)) + ((h1[0].y + h1[1].y) + (h1[2].y + h1[3].y));
+            const double s = lane_group_sum<2>(s1);
+            if (live1 && !(s > 1e-280 && s < 1e300)) bad = 1;
+            r1 = live1 ? cnt1 * rcp_newton(s) : 0.0;
+        } else {
+            s0 = ((h0[0].x + h0[1].x) + (h0[2].x + h0[3].x)) + ((h0[0].y + h0[1].y) + (h0[2].y + h0[3].y));
+            const double s = lane_group_sum<2>(s0);
             if (live0 && !(s > 1e-280 && s < 1e300)) bad = 1;
             r0 = live0 ? cnt0 * rcp_newton(s) : 0.0;
         }
-        if constexpr (C1 > 0) {
-            const double sx = (h1[0].x + h1[1].x) + (h1[2].x + h1[3].x);
-            const double sy = (h1[0].y + h1[1].y) + (h1[2].y + h1[3].y);
-            const double s = lane_group_sum<2>(sx + sy);
-            nrm1 = s;
-            if (live1 && !(s > 1e-280 && s < 1e300)) bad = 1;
-            r1 = live1 ? cnt1 * rcp_newton(s) : 0.0;
-        }
 
-        // B. q[k] over this lane's words (registers, then the LDS rows), then over the 4 word groups
+        // B. q[k] over this lane's words (registers and LDS rows interleaved), then over the 4 word groups
         double q[KRL];
+        auto row_topic_sums = [&](auto idx) {                // LDS slot t: q += r * row, next row requested
+            constexpr int t = decltype(idx)::value;
+            if constexpr (t < TWL) {
+                lds_row_wait(rowbuf);
+                double row[8];
+                rowbuf.unpack(row);
+                row_bcast_fmac<2 * (R1 + t)>(q, r1, row);
+                if constexpr (t + 1 < TWL) request_row(t + 1);
+                else request_row(0);                                      // for pass A of the next iteration
+            }
+        };
         {
             const double rb = row_bcast<0>(r0);            // r of slot i sits in lane 2*i of this lane's row
 #pragma unroll
             for (int j = 0; j < KRL; ++j) q[j] = rb * B[0][j];
         }
-        static_for<C0 - 1>([&](auto idx) {
+        static_for<(C0 < 4 ? C0 : 4) - 1>([&](auto idx) {
             constexpr int i = decltype(idx)::value + 1;
             row_bcast_fmac<2 * i>(q, r0, B[i]);
         });
+        row_topic_sums(StaticIndex<0>());
+        static_for<(C0 > 4 ? C0 - 4 : 0)>([&](auto idx) {
+            constexpr int i = decltype(idx)::value + 4;
+            row_bcast_fmac<2 * i>(q, r0, B[i]);
+        });
+        row_topic_sums(StaticIndex<1>());
         static_for<R1>([&](auto idx) {
             constexpr int i = decltype(idx)::value;
             row_bcast_fmac<2 * i>(q, r1, B[8 + i]);
         });
-        static_for<TWL>([&](auto idx) {
-            constexpr int t = decltype(idx)::value;
-            double row[KRL];
-#pragma unroll
-            for (int jj = 0; jj < KRL / 2; ++jj) {
-                const double2 b2 = myrows[t * (KT / 2) + 16 * jj];
-                row[2 * jj] = b2.x;
-                row[2 * jj + 1] = b2.y;
-            }
-            row_bcast_fmac<2 * (R1 + t)>(q, r1, row);
-        });
+        row_topic_sums(StaticIndex<2>());
         double u[KRL / 2];
 #pragma unroll
         for (int m = 0; m < KRL / 2; ++m) u[m] = swap32_add(q[m], q[m + KRL / 2]);
@@ -278,15 +317,15 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
             double part[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) part[w] = sp[w * KT + tid];
+            const double t_mine = tt[buf * KT + tid], alpha_k = alf[tid];
             keep_together(part);
             const double gnew = fma(t_mine, (part[0] + part[1]) + (part[2] + part[3]), alpha_k);   // :185
             const double diff = fabs(gnew - gam);                         // :187
-            gam_prev = gam;
+            gpv[tid] = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
             coef.load();
-            t_mine = topic_live ? exp_digamma_minus_with(gam, psi_total, coef) : 0.0;
-            tt[(buf ^ 1) * KT + tid] = t_mine;
+            tt[(buf ^ 1) * KT + tid] = topic_live ? exp_digamma_minus_with(gam, psi_total, coef) : 0.0;
             if (tid == 0) chg[buf ^ 1] = 0ull;
         }
         ++it;
@@ -340,8 +379,10 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
             }
         }
     }
+    // c_n log(normaliser_n) from r_n = c_n / normaliser_n (the normalisers themselves were not kept)
     const bool owner0 = live0 && (c & 1) == 0, owner1 = live1 && (c & 1) == 0;
-    double term3 = (owner0 ? cnt0 * log(nrm0) : 0.0) + (owner1 ? cnt1 * log(nrm1) : 0.0);
+    const double cnt0 = (double)cntv[tid], cnt1 = (double)cntv[NT + tid];
+    double term3 = (owner0 ? cnt0 * (log(cnt0) - log(r0)) : 0.0) + (owner1 ? cnt1 * (log(cnt1) - log(r1)) : 0.0);
     double shift_term = 0.0;
     if (p.heldout) {
         if (owner0) shift_term = cnt0 * p.shift[p.term_id[lo + word0]];
@@ -352,9 +393,9 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
     }
     double term2 = 0.0, lse_term = 0.0, lgam = 0.0, gsum = 0.0;
     if (topic_live) {
-        const double t_last = tt[last * KT + tid];
+        const double t_last = tt[last * KT + tid], alpha_k = alf[tid];
         const double mass = gam - alpha_k;                                // = t_last * s
-        const double ltv = digamma(gam_prev) - psi_total;                 // log t of the last iteration
+        const double ltv = digamma(gpv[tid]) - psi_total;                 // log t of the last iteration
         term2 = ltv * mass;
         if (p.heldout) lse_term = p.topic_lse[tid] * mass;
         lgam = lgamma_pos(gam);

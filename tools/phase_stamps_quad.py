@@ -28,14 +28,14 @@ rep('''    long long moved = 0x7fffffffffffffffll;''','''    long long stamp_acc
     long long moved = 0x7fffffffffffffffll;''')
 rep('''    for (;;) {                                                            // :174''','''    { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp_prev = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     for (;;) {                                                            // :174''')
-rep('''        if (moved <= thresh || left <= 0) break;''','''        STAMP(0);   // t wait + chunk-0 FMAs + writes
-        if (moved <= thresh || left <= 0) break;''')
-rep('''        {
-            const double sx = (h0[0].x + h0[1].x) + (h0[2].x + h0[3].x);''','''        STAMP(1);       // chunk-1 FMAs (+ LDS rows) + transposes landed
-        {
-            const double sx = (h0[0].x + h0[1].x) + (h0[2].x + h0[3].x);''')
-rep('''        // B. q[k] over this lane's words (registers, then the LDS rows), then over the 4 word groups''','''        STAMP(2);       // finishing sums, reciprocals
-        // B. q[k] over this lane's words (registers, then the LDS rows), then over the 4 word groups''')
+rep('''#pragma unroll
+        for (int i = 0; i < C0; ++i) myred[i * RS + c] = a[i];''','''#pragma unroll
+        for (int i = 0; i < C0; ++i) myred[i * RS + c] = a[i];
+        STAMP(0);   // t wait + pass A over the first eight slots (+ rows 0, 1) + writes''')
+rep('''            wave_lds_exchange();                                          // the writes below stay behind the reads above''','''            STAMP(1);   // register slots 8.., row 2, first transpose landed and summed
+            wave_lds_exchange();                                          // the writes below stay behind the reads above''')
+rep('''        // B. q[k] over this lane's words (registers and LDS rows interleaved), then over the 4 word groups''','''        STAMP(2);       // second transpose, reciprocals
+        // B. q[k] over this lane's words (registers and LDS rows interleaved), then over the 4 word groups''')
 rep('''        __syncthreads();
 
         // C. gamma update by the topic threads''','''        STAMP(3);       // B FMAs + swaps + sp write
@@ -83,7 +83,7 @@ ctx.set_alpha(np.full(K, 1.0 / K)); ctx.set_eta(eta)
 ctx.estep(corpus); ctx.estep(corpus)
 g = ctx.get_gamma(corpus)
 print("documents", len(sel), "classes", [(c["kernel"], c["geometry"], c["documents"]) for c in corpus.plan()], "lds_pad", pad)
-names = ["t wait + chunk-0 FMA+wr", "chunk-1 FMA + transposes", "finish sums, rcp", "B FMA+swaps+wr", "barrier1", "C: sp read", "C: compute", "barrier2"]
+names = ["t wait + A slots 0-7 (+rows)", "A slots 8.. + transpose 1", "transpose 2, reciprocals", "B FMA+swaps+wr", "barrier1", "C: sp read", "C: compute", "barrier2"]
 for base, w in ((0, "wave0 (topic wave)"), (16, "wave3")):
     its = g[:, base + 10]
     ok = its > 0
