@@ -102,7 +102,7 @@ struct pylda_ctx {
     int quilt12 = 0;
     int gather_rows = 1;            // whole-row gather kernel for ldk 64 / 128 / 256
     int lds_pad = 0;                // A/B: extra dynamic LDS per quad workgroup (forces one workgroup per CU)
-    int quad = 1;                   // 4-wavefront documents, two per CU (K <= 128, N <= 208)
+    int quad = 1;                   // register + LDS tile kernel (estep_quad.h) for table strides 128 / 256, N <= 208
     int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
     int doc_values = 1;             // 1: per-document log-likelihoods complete (see EstepParams::want_doc_ll)
     int plan_epoch = 0;
@@ -230,17 +230,19 @@ QuiltGeom quilt_geom_for(const pylda_ctx* ctx, int n)
     if (n <= 256) return {8, 8};
     return {0, 0};
 }
-// Quad kernel (4 wavefronts per document, two documents per CU): register slots and LDS slots per
-// word group, N <= 16 * (RWL + TWL); code RWL * 100 + TWL, or 0.  TWL <= 3 keeps two workgroups inside
-// a CU's 160 KiB of LDS; longer documents go to the 8-wavefront quilt kernel.
+// Quad kernel (register + LDS tile on 16 word groups; estep_quad.h): K <= 128 (table stride 128): 4
+// wavefronts per document, two documents per CU; 128 < K <= 256 (stride 256): 8 wavefronts, one per CU.
+// Register slots and LDS slots per word group, N <= 16 * (RWL + TWL); code TL * 10000 + RWL * 100 + TWL,
+// or 0.  TWL <= 3: two workgroups inside a CU's 160 KiB of LDS at stride 128, one at stride 256.
 int quad_geom_for(const pylda_ctx* ctx, int n)
 {
-    if (ctx->ldk != 128 || !ctx->quad) return 0;
-    if (n <= 128) return 800;
-    if (n <= 160) return 1000;
-    if (n <= 176) return 1001;
-    if (n <= 192) return 1002;
-    if (n <= 208) return 1003;
+    if ((ctx->ldk != 128 && ctx->ldk != 256) || !ctx->quad || ctx->lds_limit < 160 * 1024) return 0;
+    const int tl = ctx->ldk / 8 * 10000;
+    if (n <= 128) return tl + 800;
+    if (n <= 160) return tl + 1000;
+    if (n <= 176) return tl + 1001;
+    if (n <= 192) return tl + 1002;
+    if (n <= 208) return tl + 1003;
     return 0;
 }
 
@@ -436,15 +438,15 @@ int launch_quilt_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     return fail(ctx, PYLDA_ERR_STATE, "no quilt kernel for KRL=%d RWL=%d", KRL, L.rn);
 }
 
-template <int KRL, int RWL, int TWL>
+template <int TL, int RWL, int TWL>
 int launch_quad(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
-    auto kern = estep_quad_kernel<KRL, RWL, TWL>;
-    const size_t lds = QuadLds<KRL, RWL, TWL>::total + (size_t)ctx->lds_pad;
+    auto kern = estep_quad_kernel<TL, RWL, TWL>;
+    const size_t lds = QuadLds<TL, RWL, TWL>::total + (size_t)ctx->lds_pad;
     if (lds > 64 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * kQuadWaves), lds, ctx->stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave * (TL / 4)), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PYLDA_OK;
 }
@@ -452,11 +454,16 @@ int launch_quad(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
     switch (L.rn) {
-    case 800: return launch_quad<8, 8, 0>(ctx, p, L);
-    case 1000: return launch_quad<8, 10, 0>(ctx, p, L);
-    case 1001: return launch_quad<8, 10, 1>(ctx, p, L);
-    case 1002: return launch_quad<8, 10, 2>(ctx, p, L);
-    case 1003: return launch_quad<8, 10, 3>(ctx, p, L);
+    case 160800: return launch_quad<16, 8, 0>(ctx, p, L);
+    case 161000: return launch_quad<16, 10, 0>(ctx, p, L);
+    case 161001: return launch_quad<16, 10, 1>(ctx, p, L);
+    case 161002: return launch_quad<16, 10, 2>(ctx, p, L);
+    case 161003: return launch_quad<16, 10, 3>(ctx, p, L);
+    case 320800: return launch_quad<32, 8, 0>(ctx, p, L);
+    case 321000: return launch_quad<32, 10, 0>(ctx, p, L);
+    case 321001: return launch_quad<32, 10, 1>(ctx, p, L);
+    case 321002: return launch_quad<32, 10, 2>(ctx, p, L);
+    case 321003: return launch_quad<32, 10, 3>(ctx, p, L);
     }
     return fail(ctx, PYLDA_ERR_STATE, "no quad kernel for geometry %d", L.rn);
 }

@@ -322,15 +322,25 @@ struct LdsRow {
         }
     }
 };
+// PIECE: bytes between the four 16-byte pieces (16 bytes x topic lanes of a group: 256 or 512)
+template <int PIECE>
 __device__ __forceinline__ void lds_row_request(LdsRow& r, const void* lds_ptr)
 {
+    static_assert(PIECE == 256 || PIECE == 512, "16 or 32 topic lanes");
     typedef __attribute__((address_space(3))) const char* lds_cptr;
     const unsigned addr = (unsigned)(uintptr_t)(lds_cptr)lds_ptr;      // LDS byte offset
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:256\n\tds_read_b128 %2, %4 offset:512\n\t"
-                 "ds_read_b128 %3, %4 offset:768"
-                 : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
-                 : "v"(addr)
-                 : "memory");
+    if constexpr (PIECE == 256)
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:256\n\tds_read_b128 %2, %4 offset:512\n\t"
+                     "ds_read_b128 %3, %4 offset:768"
+                     : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
+                     : "v"(addr)
+                     : "memory");
+    else
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:512\n\tds_read_b128 %2, %4 offset:1024\n\t"
+                     "ds_read_b128 %3, %4 offset:1536"
+                     : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
+                     : "v"(addr)
+                     : "memory");
 }
 __device__ __forceinline__ void lds_row_wait(LdsRow& r)
 {

@@ -1,79 +1,91 @@
-// Register-resident E-step kernel with FOUR wavefronts per document, two documents per CU
-// (K <= 128, N_d <= 16 * (RWL + TWL)).
+// Register + LDS tile E-step kernel on the quilt lane grid, 16 word groups per document:
 //
-// The 8-wavefront quilt kernel (estep_quilt.h) fills a CU's register file with ONE document, and
-// an inner iteration is a serial chain (normalisers -> r -> topic sums -> cross-wavefront
-// reduction -> gamma / digamma / exp -> t), so its LDS round trips, its two barriers and the
-// gamma phase (2 of 8 wavefronts busy) leave the fp64 pipes idle more than half of the time
+//   TL = 16 (64 < K <= 128):  FOUR wavefronts per document, 4 x 16 lanes each, TWO documents per CU
+//   TL = 32 (128 < K <= 256): EIGHT wavefronts per document, 2 x 32 lanes each, one document per CU
+//
+// Why four wavefronts at K <= 128.  The 8-wavefront quilt kernel (estep_quilt.h) fills a CU's
+// register file with ONE document, and an inner iteration is a serial chain (normalisers -> r ->
+// topic sums -> cross-wavefront reduction -> gamma / digamma / exp -> t), so its LDS round trips,
+// its two barriers and the gamma phase leave the fp64 pipes idle more than half of the time
 // (round-1 counters: 44 % of wave-cycles waiting).  Nothing of the same document can fill those
-// gaps; another document can.  Here a document is a 256-thread workgroup whose wavefronts each
-// sit on a different SIMD, at <= 256 VGPRs, so TWO documents are co-resident per CU and every SIMD
-// alternates between them: one document's gamma phase and exchanges hide under the other's FMAs.
+// gaps; another document can.  A document here is a 256-thread workgroup whose wavefronts each sit
+// on a different SIMD, at <= 256 VGPRs, so two documents are co-resident per CU and every SIMD
+// alternates between them (measured: 205 ns per document with two per CU, 338 ns with one).
+// At K = 256 the tile (N_d x 2 KiB = 400 KiB) leaves room for one document per CU; the same body
+// runs with eight wavefronts, and - unlike the tiered kernel of estep_qwide.h - keeps EVERY word
+// of a document of up to 208 terms on chip: nothing is re-read from L2 inside the loop.
 //
-// Lane layout inside a wavefront is the quilt's 4 x 16 grid (lane = 16*g + c: word group g, topic
-// lane c, topics 2c + 32*jj + {0,1}); a document has 16 word groups gg = 4*wave + g and word n
-// belongs to group n % 16, slot n / 16.  Slots 0 .. RWL-1 of a group live in VGPRs (RWL = 10: 160
-// words, 160 VGPRs), slots RWL .. RWL+TWL-1 as whole rows in LDS (16 * TWL KiB at K = 128: with
-// TWL <= 3 two workgroups fit a CU's 160 KiB).  LDS rows are read twice per iteration (normaliser
-// pass, topic-sum pass) as conflict-free ds_read_b128 (row stride 1 KiB = 0 mod 256 B: the 16 lanes
-// an instruction services together read 16 different 16-byte slots).
+// Layout.  lane = TL*g + c: word group g, topic lane c; a lane holds 8 values of a table row:
+// topics 2c + 2*TL*jj + {0,1}, jj < 4 (16-byte pieces, TL*16 bytes apart).  A document has 16 word
+// groups gg = (64/TL)*wave + g and word n belongs to group n % 16, slot n / 16.  Slots 0 .. RWL-1
+// of a group live in VGPRs (RWL = 10: 160 words, 160 VGPRs), slots RWL .. RWL+TWL-1 as whole rows
+// in LDS, read twice per iteration (normaliser pass, topic-sum pass) as conflict-free ds_read_b128
+// (row stride = 0 mod 256 B: the 16 lanes an instruction services together read 16 different
+// 16-byte slots).  Per-thread loop constants (alpha, previous gamma, word counts) also live in LDS.
 //
-// Normalisers: as in the quilt kernel, partial sums over a lane's 8 topics go through an LDS
-// transpose of 8 rows per word group and a lane pair finishes each word - done twice per
-// iteration (slots 0-7, then slots 8 .. RWL+TWL-1) through the same 5 KiB-per-wavefront buffer
-// (the LDS executes a wavefront's DS instructions in order, so the second set of writes may be
-// issued right behind the first set of reads).  r reaches the 16 lanes holding a word's tile entries
-// as the DPP row-broadcast operand of the FMA itself (estep_common.h row_bcast_fmac).
+// Normalisers: partial sums over a lane's 8 topics go through an LDS transpose of 8 rows per word
+// group and TL/8 lanes finish each word (DPP inside the 16-lane row, one permlane16 swap between
+// the two rows of a 32-lane group) - done twice per iteration (slots 0-7, then slots 8 ..
+// RWL+TWL-1) through the same 5 KiB-per-wavefront buffer (the LDS executes a wavefront's DS
+// instructions in order, so the second set of writes may be issued right behind the first set of
+// reads).  r reaches the lanes holding a word's tile entries as the DPP row-broadcast operand of
+// the FMA itself (estep_common.h row_bcast_fmac).
+//
+// The loop body is ordered by hand (estep_common.h, "hand-ordered FMA blocks"): FMA blocks of eight
+// independent chains, and every LDS row requested at least 16 FMAs before it is used, through ONE
+// 16-VGPR row buffer:   [32 FMAs] row 0 [32 FMAs] row 1 [16 FMAs] row 2   in both passes.
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
 
 namespace pylda {
 
-constexpr int kQuadWaves = 4;
-
-template <int KRL, int RWL, int TWL>
+template <int TL, int RWL, int TWL>
 struct QuadLds {
-    static constexpr int W = kQuadWaves;
-    static constexpr int kTopics = 16 * KRL;
-    static constexpr int kRedStride = 20;                                          // see QuiltLds (8 rows per group)
-    static constexpr size_t red = 0;                                               // [W][4][8][kRedStride]
-    static constexpr size_t sp = red + (size_t)W * 4 * 8 * kRedStride * 8;         // [W][kTopics]
-    static constexpr size_t tt = sp + (size_t)W * kTopics * 8;                     // [2][kTopics]
+    static constexpr int W = TL / 4;                                               // wavefronts per document
+    static constexpr int G = kWave / TL;                                           // word groups per wavefront
+    static constexpr int kTopics = 8 * TL;
+    static constexpr int kRedStride = TL == 16 ? 20 : 40;                          // conflict-free b128 read-back (QuiltLds / QwideLds)
+    static constexpr size_t red_wave = (size_t)G * 8 * kRedStride * 8;             // 5120 B
+    static_assert(red_wave >= (size_t)kTopics * 8, "a wavefront's topic partials fit in its transpose area");
+    static constexpr size_t red = 0;                                               // [W][G][8][kRedStride]; reused for the W x kTopics partial sums
+    static constexpr size_t tt = red + (size_t)W * red_wave;                       // [2][kTopics]
     static constexpr size_t chg = tt + (size_t)2 * kTopics * 8;                    // u64[2]
     static constexpr size_t misc = chg + 16;                                       // [8][W]
-    static constexpr size_t alf = misc + (size_t)8 * W * 8;                        // [kTopics] alpha (0 beyond K)
+    static constexpr size_t alf = misc + (size_t)8 * W * 8;                        // [kTopics] alpha (1 beyond K)
     static constexpr size_t gpv = alf + (size_t)kTopics * 8;                       // [kTopics] gamma before the last update
     static constexpr size_t cnt = gpv + (size_t)kTopics * 8;                       // int32 [2][W * 64] counts of the words a lane finishes
     static constexpr size_t rows = (cnt + (size_t)2 * W * 64 * 4 + 255) & ~(size_t)255;   // [16][TWL][kTopics]
-    static_assert(TWL < 3 || 2 * ((cnt + (size_t)2 * W * 64 * 4 + 255) / 256 * 256 + (size_t)16 * TWL * kTopics * 8) <= 160 * 1024, "two workgroups per CU");
     static constexpr size_t total = rows + (size_t)16 * TWL * kTopics * 8;
+    static_assert(TL != 16 || 2 * total <= 160 * 1024, "K <= 128: two workgroups per CU");
+    static_assert(total <= 160 * 1024, "fits the LDS");
 };
 
-template <int KRL, int RWL, int TWL>
-__global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepParams p)
+template <int TL, int RWL, int TWL>
+__global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepParams p)
 {
-    using L = QuadLds<KRL, RWL, TWL>;
-    constexpr int W = kQuadWaves;
+    using L = QuadLds<TL, RWL, TWL>;
+    constexpr int W = L::W, G = L::G;
     constexpr int NT = kWave * W;
-    constexpr int KT = 16 * KRL;            // padded topic count (== ldk)
+    constexpr int KT = 8 * TL;              // padded topic count (== ldk)
+    constexpr int KRL = 8;                  // values of a row per lane
     constexpr int WPG = RWL + TWL;          // word slots per group
     constexpr int C0 = WPG < 8 ? WPG : 8;   // slots finished in the first transpose
     constexpr int C1 = WPG - C0;            // ... in the second
     constexpr int R1 = RWL > 8 ? RWL - 8 : 0;   // register slots of the second chunk
     constexpr int RS = L::kRedStride;
-    constexpr int QV = KRL / 4;
-    static_assert(KRL == 8, "ldk 128");
+    constexpr int FL = TL / 8;              // lanes that finish one normaliser (2 or 4)
+    constexpr int QV = KRL / G;             // topic values per lane after the in-wavefront reduction (2 or 4)
+    static_assert(TL == 16 || TL == 32, "ldk 128 or 256");
     static_assert(RWL >= 2 && RWL <= 10 && TWL >= 0 && WPG <= 16, "word slots per group");
     static_assert(TWL == 0 || RWL >= 8, "LDS slots belong to the second chunk");
+    static_assert(C0 == 8 || TWL == 0, "LDS slots need the eight-slot first chunk");
     static_assert(KT <= NT, "one thread per topic in the gamma phase");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem + L::red);
-    double* sp = reinterpret_cast<double*>(smem + L::sp);
     double* tt = reinterpret_cast<double*>(smem + L::tt);
     unsigned long long* chg = reinterpret_cast<unsigned long long*>(smem + L::chg);
     double* misc = reinterpret_cast<double*>(smem + L::misc);
-    // per-thread constants of the inner loop live in LDS, not in VGPRs (the tile takes 160 of 256):
     double* alf = reinterpret_cast<double*>(smem + L::alf);
     double* gpv = reinterpret_cast<double*>(smem + L::gpv);
     int* cntv = reinterpret_cast<int*>(smem + L::cnt);
@@ -81,23 +93,26 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    const int g = lane >> 4, c = lane & 15;
-    const int gg = wave * 4 + g;            // word group of this lane: words gg, gg + 16, gg + 32, ...
+    const int g = lane / TL, c = lane % TL;
+    const int cl = lane & 15;               // position inside the 16-lane row
+    const int half = (lane >> 4) & (TL / 16 - 1);   // row of a 32-lane group
+    const int gg = wave * G + g;            // word group of this lane: words gg, gg + 16, gg + 32, ...
     const int K = p.K, ldk = p.ldk;
     const int doc = p.order[blockIdx.x];
     const int64_t lo = p.doc_ptr[doc];
     const int N = (int)(p.doc_ptr[doc + 1] - lo);
     const double2* table = reinterpret_cast<const double2*>(p.expElog);
     const int ldk2 = ldk / 2;
-    // this lane group's tail rows in LDS: [TWL][KT] doubles, the lane reads 16-byte pieces c + 16*jj
+    // this lane group's rows in LDS: [TWL][KT] doubles, the lane reads 16-byte pieces c + TL*jj
     double2* myrows = reinterpret_cast<double2*>(smem + L::rows) + (size_t)gg * TWL * (KT / 2) + c;
 
     // ---- small loads first: they must not queue behind the tile gather (vmcnt retires in order) ----
     int wid[WPG];
 #pragma unroll
     for (int s = 0; s < WPG; ++s) wid[s] = s * 16 + gg < N ? p.term_id[lo + s * 16 + gg] : -1;
-    // the words whose normalisers this lane finishes (with its pair lane c ^ 1): slots c/2 and 8 + c/2
-    const int slot0 = c >> 1, slot1 = 8 + (c >> 1);
+    // the words whose normalisers this lane finishes (one of FL lanes): slots cl/2 and 8 + cl/2 of its group
+    const int slot0 = cl >> 1, slot1 = 8 + (cl >> 1);
+    const int part = (cl & 1) + 2 * half;
     const int word0 = slot0 * 16 + gg, word1 = slot1 * 16 + gg;
     const bool live0 = slot0 < C0 && word0 < N;
     const bool live1 = C1 > 0 && slot1 < WPG && word1 < N;
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
             const double2* row = table + (size_t)wid[i] * ldk2 + c;
 #pragma unroll
             for (int jj = 0; jj < KRL / 2; ++jj) {
-                const double2 v2 = row[16 * jj];
+                const double2 v2 = row[TL * jj];
                 B[i][2 * jj] = v2.x;
                 B[i][2 * jj + 1] = v2.y;
             }
@@ -134,13 +149,13 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
         if (wid[RWL + t] >= 0) {
             const double2* row = table + (size_t)wid[RWL + t] * ldk2 + c;
 #pragma unroll
-            for (int jj = 0; jj < KRL / 2; ++jj) v2[jj] = row[16 * jj];
+            for (int jj = 0; jj < KRL / 2; ++jj) v2[jj] = row[TL * jj];
         } else {
 #pragma unroll
             for (int jj = 0; jj < KRL / 2; ++jj) v2[jj] = double2{0.0, 0.0};
         }
 #pragma unroll
-        for (int jj = 0; jj < KRL / 2; ++jj) myrows[t * (KT / 2) + 16 * jj] = v2[jj];
+        for (int jj = 0; jj < KRL / 2; ++jj) myrows[t * (KT / 2) + TL * jj] = v2[jj];
     }
 
     // ---- total token count (:162) and the invariant sum_k gamma_k ----
@@ -165,8 +180,15 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
     double r0 = 0.0, r1 = 0.0;
     int it = 0;
     int bad = 0;
-    double* myred = red + (size_t)wave * 4 * 8 * RS + (size_t)g * 8 * RS;         // this lane group's 8 rows
-    const double2* mysrc = reinterpret_cast<const double2*>(myred + (c >> 1) * RS) + (c & 1);
+    double* myred = red + (size_t)wave * (L::red_wave / 8) + (size_t)g * 8 * RS;  // this lane group's 8 rows
+    const double2* mysrc = reinterpret_cast<const double2*>(myred + (cl >> 1) * RS) + part;
+    // this lane's share of its word's TL partials (4 pieces of 16 bytes), then over the word's FL lanes
+    auto finish_sum = [&](const double2 (&h)[4]) {
+        double s = ((h[0].x + h[1].x) + (h[2].x + h[3].x)) + ((h[0].y + h[1].y) + (h[2].y + h[3].y));
+        s = lane_group_sum<2>(s);                          // the word's other lane of this 16-lane row
+        if constexpr (TL == 32) s = swap16_add(s, s);      // ... and the two lanes of the group's other row
+        return s;
+    };
     // stop test: integer compare on the fixed-point sum, evaluated behind the first half of the next
     // iteration (see estep_quilt.h)
     const double thresh_f = p.tol * K * kChangeScale;
@@ -177,23 +199,20 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
     double tq[KRL];
 #pragma unroll
     for (int jj = 0; jj < KRL / 2; ++jj) {
-        const double2 t2 = reinterpret_cast<const double2*>(tt)[c + 16 * jj];
+        const double2 t2 = reinterpret_cast<const double2*>(tt)[c + TL * jj];
         tq[2 * jj] = t2.x;
         tq[2 * jj + 1] = t2.y;
     }
 #pragma unroll
     for (int j = 0; j < KRL; ++j) asm volatile("" : "+v"(tq[j]));
     ExpDigammaScalarCoef coef;
-    // The loop body is ordered by hand (estep_common.h, "hand-ordered FMA blocks"): FMA blocks of eight
-    // independent chains, and every LDS row requested one block of >= 16 FMAs before it is used, through
-    // ONE 16-VGPR row buffer:   [32 FMAs] row 0 [32 FMAs] row 1 [16 FMAs] row 2   in both passes.
     LdsRow rowbuf;
-    auto request_row = [&](int t) { lds_row_request(rowbuf, myrows + t * (KT / 2)); };
+    auto request_row = [&](int t) { lds_row_request<TL * 16>(rowbuf, myrows + t * (KT / 2)); };
     if constexpr (TWL > 0) request_row(0);
     for (;;) {                                                            // :174
         const int buf = it & 1;
 
-        // A. partial normalisers over this lane's topics -> LDS transpose -> sum over the 16 topic lanes
+        // A. partial normalisers over this lane's topics -> LDS transpose -> sum over the TL topic lanes
         double a[8];
         double pr[TWL > 0 ? TWL : 1];
         auto row_partial = [&](auto idx) {                   // LDS slot t: partial normaliser, next row requested
@@ -206,7 +225,6 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
                 if constexpr (t + 1 < TWL) request_row(t + 1);
             }
         };
-        static_assert(C0 == 8 || TWL == 0, "LDS slots need the eight-slot first chunk");
         if constexpr (C0 == 8) {
             col_mul8(a, B[0][0], B[1][0], B[2][0], B[3][0], B[4][0], B[5][0], B[6][0], B[7][0], tq[0]);
             col_fmac8(a, B[0][1], B[1][1], B[2][1], B[3][1], B[4][1], B[5][1], B[6][1], B[7][1], tq[1]);
@@ -231,16 +249,15 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
         wave_lds_exchange();
         double2 h0[4];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) h0[x] = mysrc[2 * x];                 // this lane's half of its word's 16 partials
+        for (int x = 0; x < 4; ++x) h0[x] = mysrc[FL * x];
         const double cnt0 = (double)cntv[tid];
-        double s0, s1 = 1.0, cnt1 = 0.0;
         if constexpr (C1 > 0) {
             double a1[R1 > 0 ? R1 : 1];
 #pragma unroll
             for (int i = 0; i < R1; ++i) a1[i] = dot8(B[8 + i], tq);
             row_partial(StaticIndex<2>());
             if constexpr (TWL > 0) request_row(0);                        // for pass B
-            s0 = ((h0[0].x + h0[1].x) + (h0[2].x + h0[3].x)) + ((h0[0].y + h0[1].y) + (h0[2].y + h0[3].y));
+            double s0 = finish_sum(h0);
             asm volatile("" : "+v"(s0));                                  // h0 is dead from here on
             wave_lds_exchange();                                          // the writes below stay behind the reads above
 #pragma unroll
@@ -250,25 +267,21 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
             wave_lds_exchange();
             double2 h1[4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) h1[x] = mysrc[2 * x];
-            cnt1 = (double)cntv[NT + tid];
-            {   // the reciprocal chain of the first chunk runs while the second transpose is in flight
-                const double s = lane_group_sum<2>(s0);
-                if (live0 && !(s > 1e-280 && s < 1e300)) bad = 1;
-                r0 = live0 ? cnt0 * rcp_newton(s) : 0.0;
-            }
-            s1 = ((h1[0].x + h1[1].x) + (h1[2].x + h1[3].x)) + ((h1[0].y + h1[1].y) + (h1[2].y + h1[3].y));
-            const double s = lane_group_sum<2>(s1);
-            if (live1 && !(s > 1e-280 && s < 1e300)) bad = 1;
-            r1 = live1 ? cnt1 * rcp_newton(s) : 0.0;
+            for (int x = 0; x < 4; ++x) h1[x] = mysrc[FL * x];
+            const double cnt1 = (double)cntv[NT + tid];
+            // the reciprocal chain of the first chunk runs while the second transpose is in flight
+            if (live0 && !(s0 > 1e-280 && s0 < 1e300)) bad = 1;
+            r0 = live0 ? cnt0 * rcp_newton(s0) : 0.0;
+            const double s1 = finish_sum(h1);
+            if (live1 && !(s1 > 1e-280 && s1 < 1e300)) bad = 1;
+            r1 = live1 ? cnt1 * rcp_newton(s1) : 0.0;
         } else {
-            s0 = ((h0[0].x + h0[1].x) + (h0[2].x + h0[3].x)) + ((h0[0].y + h0[1].y) + (h0[2].y + h0[3].y));
-            const double s = lane_group_sum<2>(s0);
-            if (live0 && !(s > 1e-280 && s < 1e300)) bad = 1;
-            r0 = live0 ? cnt0 * rcp_newton(s) : 0.0;
+            const double s0 = finish_sum(h0);
+            if (live0 && !(s0 > 1e-280 && s0 < 1e300)) bad = 1;
+            r0 = live0 ? cnt0 * rcp_newton(s0) : 0.0;
         }
 
-        // B. q[k] over this lane's words (registers and LDS rows interleaved), then over the 4 word groups
+        // B. q[k] over this lane's words (registers and LDS rows interleaved), then over the word groups
         double q[KRL];
         auto row_topic_sums = [&](auto idx) {                // LDS slot t: q += r * row, next row requested
             constexpr int t = decltype(idx)::value;
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
             }
         };
         {
-            const double rb = row_bcast<0>(r0);            // r of slot i sits in lane 2*i of this lane's row
+            const double rb = row_bcast<0>(r0);            // r of slot i sits in lane 2*i of every 16-lane row of the group
 #pragma unroll
             for (int j = 0; j < KRL; ++j) q[j] = rb * B[0][j];
         }
@@ -301,25 +314,42 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
             row_bcast_fmac<2 * i>(q, r1, B[8 + i]);
         });
         row_topic_sums(StaticIndex<2>());
-        double u[KRL / 2];
+        // over the word groups of the wavefront; the per-wavefront partials go to the (now idle) transpose area
+        wave_lds_exchange();
+        double* mysp = red + (size_t)wave * (L::red_wave / 8);
+        if constexpr (TL == 16) {
+            double u[KRL / 2];
 #pragma unroll
-        for (int m = 0; m < KRL / 2; ++m) u[m] = swap32_add(q[m], q[m + KRL / 2]);
+            for (int m = 0; m < KRL / 2; ++m) u[m] = swap32_add(q[m], q[m + KRL / 2]);
 #pragma unroll
-        for (int m = 0; m < QV; ++m) {
-            const double v = swap16_add(u[m], u[m + QV]);
-            const int slot = m + (g & 1) * QV + (g >> 1) * (KRL / 2);      // register index j of the topic
-            sp[wave * KT + 2 * c + (slot & 1) + 32 * (slot >> 1)] = v;
+            for (int m = 0; m < QV; ++m) {
+                const double v = swap16_add(u[m], u[m + QV]);
+                const int j = m + (g & 1) * QV + (g >> 1) * (KRL / 2);     // register index of the topic
+                mysp[2 * c + (j & 1) + 2 * TL * (j >> 1)] = v;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < QV; ++m) {
+                const double v = swap32_add(q[m], q[m + QV]);
+                const int j = m + g * QV;
+                mysp[2 * c + (j & 1) + 2 * TL * (j >> 1)] = v;
+            }
         }
         __syncthreads();
 
         // C. gamma update by the topic threads
         if (topic_thread) {
-            double part[W];
+            double part_sum[W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) part[w] = sp[w * KT + tid];
+            for (int w = 0; w < W; ++w) part_sum[w] = red[(size_t)w * (L::red_wave / 8) + tid];
             const double t_mine = tt[buf * KT + tid], alpha_k = alf[tid];
-            keep_together(part);
-            const double gnew = fma(t_mine, (part[0] + part[1]) + (part[2] + part[3]), alpha_k);   // :185
+            keep_together(part_sum);
+            double s0 = part_sum[0] + part_sum[1], s1 = part_sum[2] + part_sum[3];
+            if constexpr (W == 8) {
+                s0 += part_sum[4] + part_sum[5];
+                s1 += part_sum[6] + part_sum[7];
+            }
+            const double gnew = fma(t_mine, s0 + s1, alpha_k);            // :185
             const double diff = fabs(gnew - gam);                         // :187
             gpv[tid] = gam;
             gam = gnew;                                                   // :188
@@ -334,7 +364,7 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
         moved = (long long)chg[buf];
 #pragma unroll
         for (int jj = 0; jj < KRL / 2; ++jj) {
-            const double2 t2 = reinterpret_cast<const double2*>(tt + (buf ^ 1) * KT)[c + 16 * jj];
+            const double2 t2 = reinterpret_cast<const double2*>(tt + (buf ^ 1) * KT)[c + TL * jj];
             tq[2 * jj] = t2.x;
             tq[2 * jj + 1] = t2.y;
         }
@@ -354,7 +384,7 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
     // ---- document terms (:195-204) with the last phi = B t r (see estep_slab.h) ----
 #pragma unroll
     for (int jj = 0; jj < KRL / 2; ++jj) {
-        const double2 t2 = reinterpret_cast<const double2*>(tt + last * KT)[c + 16 * jj];
+        const double2 t2 = reinterpret_cast<const double2*>(tt + last * KT)[c + TL * jj];
         tq[2 * jj] = t2.x;
         tq[2 * jj + 1] = t2.y;
     }
@@ -372,7 +402,7 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
                 double gsum2 = 0.0;
 #pragma unroll
                 for (int jj = 0; jj < KRL / 2; ++jj) {
-                    const double2 g2 = row[16 * jj];
+                    const double2 g2 = row[TL * jj];
                     gsum2 = fma(g2.y, tq[2 * jj + 1], fma(g2.x, tq[2 * jj], gsum2));
                 }
                 term1 = fma(rl[s], gsum2, term1);
@@ -380,7 +410,7 @@ __global__ __launch_bounds__(kWave* kQuadWaves, 2) void estep_quad_kernel(EstepP
         }
     }
     // c_n log(normaliser_n) from r_n = c_n / normaliser_n (the normalisers themselves were not kept)
-    const bool owner0 = live0 && (c & 1) == 0, owner1 = live1 && (c & 1) == 0;
+    const bool owner0 = live0 && part == 0, owner1 = live1 && part == 0;
     const double cnt0 = (double)cntv[tid], cnt1 = (double)cntv[NT + tid];
     double term3 = (owner0 ? cnt0 * (log(cnt0) - log(r0)) : 0.0) + (owner1 ? cnt1 * (log(cnt1) - log(r1)) : 0.0);
     double shift_term = 0.0;

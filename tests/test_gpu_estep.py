@@ -228,6 +228,33 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
 
 
+@pytest.mark.parametrize("K,V,mean_len", [(256, 2500, 190), (256, 2500, 120), (200, 2500, 175), (129, 2000, 60)])
+def test_wide_table_kernels_agree(capi, K, V, mean_len):
+    """128 < K <= 256 (table stride 256): the 8-wavefront quad kernel (all words on chip), the wide tiered, hybrid
+    and streaming kernels against the C oracle and the generic kernel, training and held-out, bitwise repeatable."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(K * 11 + mean_len)
+    ptr, ids, cts = random_corpus(rng, 36, V, mean_len, zipf=0.8)
+    eta = rng.gamma(100.0, 0.01, (K, V))
+    eta[:, rng.choice(V, V // 4, replace=False)] = 1.0 / V
+    alpha = rng.uniform(0.05, 1.5, K)
+    ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
+    gen = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 1)])
+    held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
+    for variant in (10, 9, 8, 7):
+        out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
+        check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
+        assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+        assert np.mean(out["iters"] == gen["iters"]) >= 0.95
+        assert rel_err(out["gamma"], gen["gamma"]) < 1e-9
+        held = run(capi, alpha, eta, ptr, ids, cts, heldout=True, options=[("force_variant", variant)])
+        check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"],
+                      ll_key="doc_words_ll", min_same=0.95)
+        again = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
+        assert np.array_equal(out["gamma"], again["gamma"]) and np.array_equal(out["sstats"], again["sstats"])
+        assert np.array_equal(out["doc_ll"], again["doc_ll"])
+
+
 @pytest.mark.parametrize("variant", [1, 3, 4, 6, 7, 8, 9, 10])
 def test_training_fast_path_corpus_likelihood(capi, ap_train, variant):
     """Option doc_values=0 (what learning() uses): the corpus-level document_log_likelihood must equal
@@ -288,7 +315,8 @@ def test_nips_k500_matches_reference_goldens(capi):
     check_against(held, g["heldout_gamma"], g["heldout_words_ll"], g["heldout_iters"], ll_key="doc_words_ll")
 
 
-@pytest.mark.parametrize("K,V,mean_len", [(100, 900, 150), (128, 1200, 210), (256, 3000, 190), (256, 3000, 330)])
+@pytest.mark.parametrize("K,V,mean_len", [(100, 900, 150), (128, 1200, 210), (256, 3000, 190), (256, 3000, 330),
+                                          (256, 3000, 150), (200, 3000, 120)])
 def test_iteration_cap_and_threshold_on_register_kernels(capi, K, V, mean_len):
     """The register-resident kernels evaluate the stop test of iteration i behind the first half of
     iteration i+1 (an integer compare on a fixed-point sum): caps, loose / zero / negative thresholds

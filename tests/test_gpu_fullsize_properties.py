@@ -20,8 +20,8 @@ CONFIGS = {
 @pytest.fixture(scope="module", params=["cfg3", "cfg4"])
 def cfg3(request):
     """cfg 3: synthetic LDA corpus, 100,000 documents, V=50,000, K=128 (quilt kernels);
-    cfg 4: 1,000,000 documents, V=100,000, K=256 (wide tiered kernels, incl. the multi-round class for the
-    29 documents with more than 256 distinct terms).  Same generator, seeds and sizes as bench.py."""
+    cfg 4: 1,000,000 documents, V=100,000, K=256 (8-wavefront quad kernels up to 208 distinct terms, wide tiered
+    kernels beyond, incl. the multi-round class for the 29 documents with more than 256 distinct terms).  Same generator, seeds and sizes as bench.py."""
     import bench
     from pylda_amd import _capi
     from pylda_amd.corpus import corpus_checksum, synthetic_lda_shard
@@ -107,7 +107,8 @@ def test_oracle_spot_check_on_full_size_run(cfg3):
     if c["name"] == "cfg4":             # the longest have > 256 distinct terms: the wide kernel's multi-round class
         assert np.diff(c["ptr"])[order[-1]] > 256
         kernels = {(p["kernel"], p["geometry"]) for p in c["corpus"].plan()}
-        assert ("qwide", 1) in kernels and ("qwide", 2) in kernels, kernels
+        assert ("qwide", 1) in kernels and ("qwide", 2) in kernels, kernels       # 209..256 and > 256 distinct terms
+        assert ("quad", 321003) in kernels and ("quad", 321002) in kernels, kernels   # the bulk: all words on chip
     from conftest import csr_slice
     ptr, tid, tct = csr_slice(c["ptr"], c["ids"], c["cts"], docs)
     ref = c_oracle.e_step(c["alpha"], c["eta"], ptr, tid, tct)
