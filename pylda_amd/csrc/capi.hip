@@ -243,6 +243,7 @@ int quad_geom_for(const pylda_ctx* ctx, int n)
     if (n <= 176) return tl + 1001;
     if (n <= 192) return tl + 1002;
     if (n <= 208) return tl + 1003;
+    if (n <= 224 && ctx->ldk == 256) return tl + 1004;
     return 0;
 }
 
@@ -464,6 +465,7 @@ int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     case 321001: return launch_quad<32, 10, 1>(ctx, p, L);
     case 321002: return launch_quad<32, 10, 2>(ctx, p, L);
     case 321003: return launch_quad<32, 10, 3>(ctx, p, L);
+    case 321004: return launch_quad<32, 10, 4>(ctx, p, L);
     }
     return fail(ctx, PYLDA_ERR_STATE, "no quad kernel for geometry %d", L.rn);
 }

@@ -202,6 +202,13 @@ __device__ __forceinline__ void row_bcast_all(double v, double* out)
 // v_mov_dpp pair per word.  The DPP read of r needs two wait states behind the VALU write of r and
 // the compiler's hazard recogniser does not look inside inline assembly: callers put other VALU
 // work (row_bcast_matvec: the first word's plain multiplies) between the two.
+// A value about to be read through the DPP operand of an asm FMA block: two wait states behind its
+// (compiler-generated) VALU write, wherever the scheduler ends up placing that write.  Found the hard
+// way: with the word count arriving late from memory the compiler sank `r = count * reciprocal` to
+// right in front of the first v_fmac_f64_dpp, which then read the previous iteration's low half
+// (errors of 1e-8 in the topics of the block's first chain only).
+__device__ __forceinline__ void dpp_source_ready(double& r) { asm volatile("s_nop 1" : "+v"(r)); }
+
 #define PYLDA_DPP_ROW(L) " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n\t"
 template <int L>
 __device__ __forceinline__ void row_bcast_fmac(double (&q)[8], double r, const double (&b)[8])

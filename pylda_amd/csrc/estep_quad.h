@@ -40,13 +40,25 @@
 
 namespace pylda {
 
+#ifndef PYLDA_QUAD_FORCE_PRE
+#define PYLDA_QUAD_FORCE_PRE 0
+#endif
+#ifndef PYLDA_QUAD_FORCE_GCNT
+#define PYLDA_QUAD_FORCE_GCNT 0
+#endif
+
 template <int TL, int RWL, int TWL>
 struct QuadLds {
     static constexpr int W = TL / 4;                                               // wavefronts per document
     static constexpr int G = kWave / TL;                                           // word groups per wavefront
     static constexpr int kTopics = 8 * TL;
-    static constexpr int kRedStride = TL == 16 ? 20 : 40;                          // conflict-free b128 read-back (QuiltLds / QwideLds)
-    static constexpr size_t red_wave = (size_t)G * 8 * kRedStride * 8;             // 5120 B
+    // kPre (stride 256, four LDS slots): neighbouring lanes add their partial normalisers before the
+    // transpose (one DPP level, 3 instructions per word) so that it takes half the LDS - which, with
+    // the word counts re-read from global memory, is what lets 64 rows of 2 KiB fit beside it.
+    static constexpr bool kPre = TL == 32 && (TWL >= 4 || PYLDA_QUAD_FORCE_PRE);
+    static constexpr int kPartials = kPre ? 16 : TL;                               // partial sums per word in the transpose
+    static constexpr int kRedStride = kPartials == 16 ? 20 : 40;                   // conflict-free b128 read-back (QuiltLds / QwideLds)
+    static constexpr size_t red_wave = (size_t)G * 8 * kRedStride * 8;             // 5120 B (kPre: 2560 B)
     static_assert(red_wave >= (size_t)kTopics * 8, "a wavefront's topic partials fit in its transpose area");
     static constexpr size_t red = 0;                                               // [W][G][8][kRedStride]; reused for the W x kTopics partial sums
     static constexpr size_t tt = red + (size_t)W * red_wave;                       // [2][kTopics]
@@ -55,7 +67,8 @@ struct QuadLds {
     static constexpr size_t alf = misc + (size_t)8 * W * 8;                        // [kTopics] alpha (1 beyond K)
     static constexpr size_t gpv = alf + (size_t)kTopics * 8;                       // [kTopics] gamma before the last update
     static constexpr size_t cnt = gpv + (size_t)kTopics * 8;                       // int32 [2][W * 64] counts of the words a lane finishes
-    static constexpr size_t rows = (cnt + (size_t)2 * W * 64 * 4 + 255) & ~(size_t)255;   // [16][TWL][kTopics]
+    static constexpr bool kGlobalCounts = (TL == 32 && TWL >= 4) || PYLDA_QUAD_FORCE_GCNT;
+    static constexpr size_t rows = (cnt + (kGlobalCounts ? 0 : (size_t)2 * W * 64 * 4) + 255) & ~(size_t)255;   // [16][TWL][kTopics]
     static constexpr size_t total = rows + (size_t)16 * TWL * kTopics * 8;
     static_assert(TL != 16 || 2 * total <= 160 * 1024, "K <= 128: two workgroups per CU");
     static_assert(total <= 160 * 1024, "fits the LDS");
@@ -75,9 +88,11 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     constexpr int R1 = RWL > 8 ? RWL - 8 : 0;   // register slots of the second chunk
     constexpr int RS = L::kRedStride;
     constexpr int FL = TL / 8;              // lanes that finish one normaliser (2 or 4)
+    constexpr bool PRE = L::kPre;
+    constexpr int NPIECE = L::kPartials / 2 / FL;   // 16-byte pieces of the transpose each of them reads (4; kPre: 2)
     constexpr int QV = KRL / G;             // topic values per lane after the in-wavefront reduction (2 or 4)
     static_assert(TL == 16 || TL == 32, "ldk 128 or 256");
-    static_assert(RWL >= 2 && RWL <= 10 && TWL >= 0 && WPG <= 16, "word slots per group");
+    static_assert(RWL >= 2 && RWL <= 10 && TWL >= 0 && TWL <= 4 && WPG <= 16, "word slots per group");
     static_assert(TWL == 0 || RWL >= 8, "LDS slots belong to the second chunk");
     static_assert(C0 == 8 || TWL == 0, "LDS slots need the eight-slot first chunk");
     static_assert(KT <= NT, "one thread per topic in the gamma phase");
@@ -116,8 +131,23 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     const int word0 = slot0 * 16 + gg, word1 = slot1 * 16 + gg;
     const bool live0 = slot0 < C0 && word0 < N;
     const bool live1 = C1 > 0 && slot1 < WPG && word1 < N;
-    cntv[tid] = live0 ? p.term_ct[lo + word0] : 0;
-    cntv[NT + tid] = live1 ? p.term_ct[lo + word1] : 0;
+    constexpr bool GCNT = L::kGlobalCounts;
+    if constexpr (!GCNT) {
+        cntv[tid] = live0 ? p.term_ct[lo + word0] : 0;
+        cntv[NT + tid] = live1 ? p.term_ct[lo + word1] : 0;
+    }
+    // kPre: no LDS left for the counts - re-read from global memory every iteration (an L1 / L2 hit requested
+    // a whole pass before it is used); the empty asm keeps the compiler from hoisting the load into a VGPR
+    auto count_of = [&](int which) -> double {
+        if constexpr (GCNT) {
+            int64_t at = lo + (which ? (live1 ? word1 : 0) : (live0 ? word0 : 0));
+            asm volatile("" : "+v"(at));
+            const int ct = p.term_ct[at];
+            return (which ? live1 : live0) ? (double)ct : 0.0;
+        } else {
+            return (double)cntv[which * NT + tid];
+        }
+    };
     double local = 0.0;
     for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
     double asum = 0.0;
@@ -182,9 +212,12 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     int bad = 0;
     double* myred = red + (size_t)wave * (L::red_wave / 8) + (size_t)g * 8 * RS;  // this lane group's 8 rows
     const double2* mysrc = reinterpret_cast<const double2*>(myred + (cl >> 1) * RS) + part;
-    // this lane's share of its word's TL partials (4 pieces of 16 bytes), then over the word's FL lanes
-    auto finish_sum = [&](const double2 (&h)[4]) {
-        double s = ((h[0].x + h[1].x) + (h[2].x + h[3].x)) + ((h[0].y + h[1].y) + (h[2].y + h[3].y));
+    const int cw = PRE ? c >> 1 : c;        // where this lane's partial goes in a transpose row
+    // this lane's share of its word's partials (NPIECE pieces of 16 bytes), then over the word's FL lanes
+    auto finish_sum = [&](const double2 (&h)[NPIECE]) {
+        double s;
+        if constexpr (NPIECE == 4) s = ((h[0].x + h[1].x) + (h[2].x + h[3].x)) + ((h[0].y + h[1].y) + (h[2].y + h[3].y));
+        else s = (h[0].x + h[1].x) + (h[0].y + h[1].y);
         s = lane_group_sum<2>(s);                          // the word's other lane of this 16-lane row
         if constexpr (TL == 32) s = swap16_add(s, s);      // ... and the two lanes of the group's other row
         return s;
@@ -240,46 +273,57 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
 #pragma unroll
             for (int i = 0; i < C0; ++i) a[i] = dot8(B[i], tq);
         }
+        if constexpr (PRE) {
+            // a DPP read needs two wait states behind the VALU write of its source, and the compiler's hazard
+            // recogniser does not look inside the asm blocks that produced a[]: the last two chains settle here
+            asm volatile("s_nop 1" : "+v"(a[C0 - 2]), "+v"(a[C0 - 1]));
+        }
 #pragma unroll
-        for (int i = 0; i < C0; ++i) myred[i * RS + c] = a[i];
+        for (int i = 0; i < C0; ++i) myred[i * RS + cw] = PRE ? lane_group_sum<2>(a[i]) : a[i];
         if (moved <= thresh || left <= 0) {                               // :189 (mean <= tol), :174
-            if constexpr (TWL > 2) lds_row_wait(rowbuf);                  // no read may land after the loop
+            if constexpr (TWL > 2) lds_row_wait(rowbuf);                  // no read may land after the loop (row 2 is in flight)
             break;
         }
         wave_lds_exchange();
-        double2 h0[4];
+        double2 h0[NPIECE];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) h0[x] = mysrc[FL * x];
-        const double cnt0 = (double)cntv[tid];
+        for (int x = 0; x < NPIECE; ++x) h0[x] = mysrc[FL * x];
+        const double cnt0 = count_of(0);
         if constexpr (C1 > 0) {
             double a1[R1 > 0 ? R1 : 1];
 #pragma unroll
             for (int i = 0; i < R1; ++i) a1[i] = dot8(B[8 + i], tq);
             row_partial(StaticIndex<2>());
+            row_partial(StaticIndex<3>());
             if constexpr (TWL > 0) request_row(0);                        // for pass B
             double s0 = finish_sum(h0);
             asm volatile("" : "+v"(s0));                                  // h0 is dead from here on
             wave_lds_exchange();                                          // the writes below stay behind the reads above
+            if constexpr (PRE && R1 > 0) asm volatile("s_nop 1" : "+v"(a1[R1 - 1]));       // (as above: dot8's last add)
+            if constexpr (PRE && TWL > 0) asm volatile("s_nop 1" : "+v"(pr[TWL - 1]));
 #pragma unroll
-            for (int i = 0; i < R1; ++i) myred[i * RS + c] = a1[i];
+            for (int i = 0; i < R1; ++i) myred[i * RS + cw] = PRE ? lane_group_sum<2>(a1[i]) : a1[i];
 #pragma unroll
-            for (int t = 0; t < TWL; ++t) myred[(R1 + t) * RS + c] = pr[t];
+            for (int t = 0; t < TWL; ++t) myred[(R1 + t) * RS + cw] = PRE ? lane_group_sum<2>(pr[t]) : pr[t];
             wave_lds_exchange();
-            double2 h1[4];
+            double2 h1[NPIECE];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) h1[x] = mysrc[FL * x];
-            const double cnt1 = (double)cntv[NT + tid];
+            for (int x = 0; x < NPIECE; ++x) h1[x] = mysrc[FL * x];
+            const double cnt1 = count_of(1);
             // the reciprocal chain of the first chunk runs while the second transpose is in flight
             if (live0 && !(s0 > 1e-280 && s0 < 1e300)) bad = 1;
             r0 = live0 ? cnt0 * rcp_newton(s0) : 0.0;
             const double s1 = finish_sum(h1);
             if (live1 && !(s1 > 1e-280 && s1 < 1e300)) bad = 1;
             r1 = live1 ? cnt1 * rcp_newton(s1) : 0.0;
+            dpp_source_ready(r1);
         } else {
             const double s0 = finish_sum(h0);
             if (live0 && !(s0 > 1e-280 && s0 < 1e300)) bad = 1;
             r0 = live0 ? cnt0 * rcp_newton(s0) : 0.0;
         }
+
+        dpp_source_ready(r0);
 
         // B. q[k] over this lane's words (registers and LDS rows interleaved), then over the word groups
         double q[KRL];
@@ -314,6 +358,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             row_bcast_fmac<2 * i>(q, r1, B[8 + i]);
         });
         row_topic_sums(StaticIndex<2>());
+        row_topic_sums(StaticIndex<3>());
         // over the word groups of the wavefront; the per-wavefront partials go to the (now idle) transpose area
         wave_lds_exchange();
         double* mysp = red + (size_t)wave * (L::red_wave / 8);
@@ -411,7 +456,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     }
     // c_n log(normaliser_n) from r_n = c_n / normaliser_n (the normalisers themselves were not kept)
     const bool owner0 = live0 && part == 0, owner1 = live1 && part == 0;
-    const double cnt0 = (double)cntv[tid], cnt1 = (double)cntv[NT + tid];
+    const double cnt0 = count_of(0), cnt1 = count_of(1);
     double term3 = (owner0 ? cnt0 * (log(cnt0) - log(r0)) : 0.0) + (owner1 ? cnt1 * (log(cnt1) - log(r1)) : 0.0);
     double shift_term = 0.0;
     if (p.heldout) {
