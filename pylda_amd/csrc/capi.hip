@@ -27,6 +27,7 @@
 #include "estep_qhybrid.h"
 #include "estep_qwide.h"
 #include "mstep_kernels.h"
+#include "postings.h"
 #include "prepare_kernels.h"
 #include "sstats_kernels.h"
 
@@ -149,8 +150,6 @@ struct pylda_corpus {
     int64_t* d_word_seg_ptr = nullptr;  // V+1
     double* d_partial = nullptr;   // nseg x ldk
     int64_t nseg = 0;
-    std::vector<int64_t> h_doc_ptr;     // kept for the lazy postings build
-    std::vector<int32_t> h_term_id;
     std::vector<int32_t> h_terms_sorted;  // distinct-term counts in schedule order
     std::vector<Launch> plan;
     int plan_epoch = 0;
@@ -566,28 +565,28 @@ int enqueue_prepare(pylda_ctx* ctx, bool heldout)
     return PYLDA_OK;
 }
 
-// Postings (CSC) of the corpus, built once, on first training E-step: for every
-// word the (document, CSR position) pairs in document order, cut into segments.
+// Postings (CSC) of the corpus, built once, on the first training E-step, on the device (postings.hip):
+// for every word the (document, CSR position) pairs in document order, cut into segments.
 int build_postings(pylda_corpus* c)
 {
     if (c->have_postings) return PYLDA_OK;
     pylda_ctx* ctx = c->ctx;
     const int V = ctx->V;
-    const int64_t D = c->D, nnz = c->nnz;
+    const int64_t nnz = c->nnz;
+    int rc = PYLDA_OK;
+    auto A = [&](int r) { if (rc == PYLDA_OK) rc = r; };
+    A(dev_alloc(ctx, &c->d_post_doc, (size_t)nnz));
+    A(dev_alloc(ctx, &c->d_post_pos, (size_t)nnz));
+    if (rc != PYLDA_OK) return rc;
     std::vector<int64_t> col_ptr((size_t)V + 1, 0);
-    for (int64_t i = 0; i < nnz; ++i) col_ptr[(size_t)c->h_term_id[i] + 1] += 1;
-    for (int v = 0; v < V; ++v) col_ptr[v + 1] += col_ptr[v];
-    std::vector<int32_t> post_doc((size_t)nnz), post_pos((size_t)nnz);
-    {
-        std::vector<int64_t> fill(col_ptr.begin(), col_ptr.end() - 1);
-        for (int64_t d = 0; d < D; ++d)
-            for (int64_t i = c->h_doc_ptr[d]; i < c->h_doc_ptr[d + 1]; ++i) {
-                const int64_t at = fill[c->h_term_id[i]]++;
-                post_doc[at] = (int32_t)d;
-                post_pos[at] = (int32_t)i;
-            }
-    }
+    const char* what = "";
+    const hipError_t e = build_postings_device(ctx->stream, V, c->D, nnz, c->d_doc_ptr, c->d_term_id, c->d_post_doc,
+                                               c->d_post_pos, col_ptr.data(), &what);
+    if (e != hipSuccess)
+        return fail(ctx, e == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     std::vector<int64_t> seg_begin, seg_end, word_seg_ptr((size_t)V + 1, 0);
+    seg_begin.reserve((size_t)(nnz / kSegment + V));
+    seg_end.reserve((size_t)(nnz / kSegment + V));
     for (int v = 0; v < V; ++v) {
         for (int64_t b = col_ptr[v]; b < col_ptr[v + 1]; b += kSegment) {
             seg_begin.push_back(b);
@@ -596,10 +595,6 @@ int build_postings(pylda_corpus* c)
         word_seg_ptr[v + 1] = (int64_t)seg_begin.size();
     }
     c->nseg = (int64_t)seg_begin.size();
-    int rc = PYLDA_OK;
-    auto A = [&](int r) { if (rc == PYLDA_OK) rc = r; };
-    A(dev_alloc(ctx, &c->d_post_doc, (size_t)nnz));
-    A(dev_alloc(ctx, &c->d_post_pos, (size_t)nnz));
     A(dev_alloc(ctx, &c->d_seg_begin, (size_t)c->nseg));
     A(dev_alloc(ctx, &c->d_seg_end, (size_t)c->nseg));
     A(dev_alloc(ctx, &c->d_word_seg_ptr, (size_t)V + 1));
@@ -609,15 +604,11 @@ int build_postings(pylda_corpus* c)
         if (rc == PYLDA_OK && bytes && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
             rc = fail(ctx, PYLDA_ERR_HIP, "postings: H2D copy failed");
     };
-    H2D(c->d_post_doc, post_doc.data(), (size_t)nnz * sizeof(int32_t));
-    H2D(c->d_post_pos, post_pos.data(), (size_t)nnz * sizeof(int32_t));
     H2D(c->d_seg_begin, seg_begin.data(), (size_t)c->nseg * sizeof(int64_t));
     H2D(c->d_seg_end, seg_end.data(), (size_t)c->nseg * sizeof(int64_t));
     H2D(c->d_word_seg_ptr, word_seg_ptr.data(), ((size_t)V + 1) * sizeof(int64_t));
     if (rc != PYLDA_OK) return rc;
     c->have_postings = true;
-    std::vector<int64_t>().swap(c->h_doc_ptr);
-    std::vector<int32_t>().swap(c->h_term_id);
     return PYLDA_OK;
 }
 
@@ -950,8 +941,6 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
         pylda_corpus_destroy(c);
         return rc;
     }
-    c->h_doc_ptr.assign(doc_ptr, doc_ptr + D + 1);     // for the lazy postings build
-    c->h_term_id.assign(term_id, term_id + nnz);
     *out = c;
     return PYLDA_OK;
 }

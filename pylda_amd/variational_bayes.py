@@ -40,6 +40,13 @@ class VariationalBayes(Inferencer):
         self._gamma_host_stale = False      # device gamma is ahead of the host copy
         self._gamma_on_device = False       # the training corpus holds the gamma of an E-step
         self._verbose = True
+        # Side effects of the reference's E-step loop that have no counterpart on the device, reproduced
+        # on request (both off by default):
+        #   _reference_rng_stream   draw (and discard) numpy.random.permutation(D) per E-step (:159) so that
+        #                           numpy's global RNG stays in step with a reference run;
+        #   _progress_lines         the "successfully processed %d documents..." lines (:209-210).
+        self._reference_rng_stream = False
+        self._progress_lines = False
 
     # ------------------------------------------------------------------ state
     @property
@@ -124,6 +131,13 @@ class VariationalBayes(Inferencer):
         self._train_csr = None
         self._train_corpus = None        # the device copy is rebuilt from the new container
 
+    def _reference_side_effects(self, number_of_documents):
+        if self.__dict__.get("_reference_rng_stream"):
+            numpy.random.permutation(number_of_documents)                      # :159 (visiting order; discarded)
+        if self.__dict__.get("_progress_lines"):
+            for done in range(1000, number_of_documents + 1, 1000):            # :209-210 (the reference prints
+                print("successfully processed %d documents..." % done)         #  doc_id + 1 in visiting order)
+
     def _push_model(self):
         ctx = self._context()
         ctx.set_alpha(self._alpha_alpha)
@@ -200,6 +214,7 @@ class VariationalBayes(Inferencer):
         if parsed_corpus is None:
             corpus = self._training_corpus()
             ctx.estep(corpus, local_parameter_iteration, local_parameter_converge_threshold, False)
+            self._reference_side_effects(corpus.D)
             document_log_likelihood, _, _ = ctx.estep_results(corpus)
             self._gamma_host_stale = self._gamma_on_device = True
             return document_log_likelihood, ctx.get_sstats()
@@ -211,6 +226,7 @@ class VariationalBayes(Inferencer):
             corpus = ctx.corpus(*lists_to_csr(word_ids, word_cts))
         try:
             ctx.estep(corpus, local_parameter_iteration, local_parameter_converge_threshold, True)
+            self._reference_side_effects(corpus.D)
             _, words_log_likelihood, _ = ctx.estep_results(corpus)
             gamma_values = ctx.get_gamma(corpus)
         finally:
@@ -252,6 +268,7 @@ class VariationalBayes(Inferencer):
 
         clock_e_step = time.time()
         ctx.estep(corpus, 50, 1e-6, False)
+        self._reference_side_effects(corpus.D)
         group = self._process_group
         if group is not None:
             from pylda_amd import distributed

@@ -256,3 +256,28 @@ def test_m_step_uses_a_host_gamma_the_caller_assigned(ap_train):
     m.e_step()
     _, ass = m.m_step(sstats)
     assert rel_err(ass, vb_numpy.m_step(eta_ref, m._alpha_beta, sstats, m._gamma)[1]) < 1e-10
+
+
+def test_reference_rng_stream_and_progress_lines(ap_train, capsys):
+    """Optional side effects of the reference's E-step loop: with _reference_rng_stream the global numpy RNG
+    advances exactly as in the reference (one permutation(D) draw per e_step, variational_bayes.py:159), and
+    _progress_lines prints its every-1000-documents lines (:209-210)."""
+    from pylda_amd.variational_bayes import VariationalBayes
+    g = ap_train
+    m = VariationalBayes()
+    m._verbose = False
+    m._initialize_parsed(g["doc_ptr"], g["term_id"], g["term_ct"], 6806, 10, 0.1, 1.0 / 6806, eta=g["eta"].copy())
+    np.random.seed(123)
+    m.e_step()
+    untouched = np.random.random()
+    m._reference_rng_stream = True
+    m._progress_lines = True
+    np.random.seed(123)
+    capsys.readouterr()
+    m.e_step()
+    after = np.random.random()
+    np.random.seed(123)
+    np.random.permutation(2000)
+    assert after == np.random.random() and after != untouched
+    assert capsys.readouterr().out.splitlines() == ["successfully processed 1000 documents...",
+                                                    "successfully processed 2000 documents..."]
