@@ -33,12 +33,45 @@ def main(root):
                 calls[k].add(r["Dispatch_Id"])
             print("== counters:", os.path.relpath(path, root))
             tot = {k: sum(v.values()) for k, v in acc.items()}
-            for k in sorted(acc, key=lambda k: -tot[k])[:6]:
+            for k in sorted(acc, key=lambda k: -tot[k])[:10]:
                 n = max(1, len(calls[k]))
                 print("  %s  (%d dispatches; per-dispatch averages)" % (k, n))
                 for c, v in sorted(acc[k].items()):
                     print("      %-24s %16.1f" % (c, v / n))
 
 
+def estep_traffic(root):
+    """HBM bytes of one E-step (document kernels + statistics pass) from the FETCH_SIZE / WRITE_SIZE passes:
+    per-dispatch averages summed over the E-step's kernels, FETCH_SIZE doubled (gfx950 counts the 128-byte
+    requests of wide coalesced reads at 64 bytes: MI355X_MICROARCH.md, HBM)."""
+    import json
+    mine = ("estep_", "sstats_")
+    out = {}
+    for counter, sub in (("FETCH_SIZE", "pmc3"), ("WRITE_SIZE", "pmc4")):
+        acc, calls = defaultdict(float), defaultdict(set)
+        for path in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(path)):
+                if r["Counter_Name"] != counter:
+                    continue
+                k = short(r["Kernel_Name"]).replace("void ", "")
+                if k.startswith(mine) and "logspace" not in k:
+                    acc[k] += float(r["Counter_Value"])
+                    calls[k].add(r["Dispatch_Id"])
+        out[counter] = {k: acc[k] / max(1, len(calls[k])) for k in acc}
+    if not out["FETCH_SIZE"]:
+        return
+    fetch_kb = sum(out["FETCH_SIZE"].values())
+    write_kb = sum(out["WRITE_SIZE"].values())
+    doc = {"FETCH_SIZE_KB_per_kernel": out["FETCH_SIZE"], "WRITE_SIZE_KB_per_kernel": out["WRITE_SIZE"],
+           "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+           "correction": "FETCH_SIZE * 2 (gfx950: 128-byte requests of wide coalesced reads are tallied at 64 bytes, "
+                         "MI355X_MICROARCH.md HBM section); WRITE_SIZE as is; KB = 1024 bytes",
+           "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024)}
+    print("== E-step traffic (per launch):", json.dumps(doc))
+    with open(os.path.join(root, "traffic.json"), "w") as fh:
+        json.dump(doc, fh, indent=1)
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    estep_traffic(sys.argv[1])
