@@ -242,7 +242,7 @@ int quad_geom_for(const pylda_ctx* ctx, int n)
     if (n <= 176) return tl + 1001;
     if (n <= 192) return tl + 1002;
     if (n <= 208) return tl + 1003;
-    if (n <= 224 && ctx->ldk == 256) return tl + 1004;
+    if (n <= 224) return tl + 1004;
     return 0;
 }
 
@@ -459,6 +459,7 @@ int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     case 161001: return launch_quad<16, 10, 1>(ctx, p, L);
     case 161002: return launch_quad<16, 10, 2>(ctx, p, L);
     case 161003: return launch_quad<16, 10, 3>(ctx, p, L);
+    case 161004: return launch_quad<16, 10, 4>(ctx, p, L);
     case 320800: return launch_quad<32, 8, 0>(ctx, p, L);
     case 321000: return launch_quad<32, 10, 0>(ctx, p, L);
     case 321001: return launch_quad<32, 10, 1>(ctx, p, L);

@@ -52,12 +52,13 @@ struct QuadLds {
     static constexpr int W = TL / 4;                                               // wavefronts per document
     static constexpr int G = kWave / TL;                                           // word groups per wavefront
     static constexpr int kTopics = 8 * TL;
-    // kPre (stride 256, four LDS slots): neighbouring lanes add their partial normalisers before the
-    // transpose (one DPP level, 3 instructions per word) so that it takes half the LDS - which, with
-    // the word counts re-read from global memory, is what lets 64 rows of 2 KiB fit beside it.
-    static constexpr bool kPre = TL == 32 && (TWL >= 4 || PYLDA_QUAD_FORCE_PRE);
-    static constexpr int kPartials = kPre ? 16 : TL;                               // partial sums per word in the transpose
-    static constexpr int kRedStride = kPartials == 16 ? 20 : 40;                   // conflict-free b128 read-back (QuiltLds / QwideLds)
+    // kPre (four LDS slots): neighbouring lanes add their partial normalisers before the transpose (one
+    // DPP level, 3 instructions per word) so that it takes half the LDS - which, with the word counts
+    // re-read from global memory, is what lets 64 rows fit beside it (stride 256: 128 KiB in one
+    // workgroup's 160 KiB; stride 128: 64 KiB in each of two workgroups' 80 KiB).
+    static constexpr bool kPre = TWL >= 4 || (TL == 32 && PYLDA_QUAD_FORCE_PRE);
+    static constexpr int kPartials = kPre ? TL / 2 : TL;                           // partial sums per word in the transpose
+    static constexpr int kRedStride = kPartials == 8 ? 10 : kPartials == 16 ? 20 : 40;   // 16-byte aligned rows, b128 read-back (QuiltLds / QwideLds)
     static constexpr size_t red_wave = (size_t)G * 8 * kRedStride * 8;             // 5120 B (kPre: 2560 B)
     static_assert(red_wave >= (size_t)kTopics * 8, "a wavefront's topic partials fit in its transpose area");
     static constexpr size_t red = 0;                                               // [W][G][8][kRedStride]; reused for the W x kTopics partial sums
@@ -67,7 +68,7 @@ struct QuadLds {
     static constexpr size_t alf = misc + (size_t)8 * W * 8;                        // [kTopics] alpha (1 beyond K)
     static constexpr size_t gpv = alf + (size_t)kTopics * 8;                       // [kTopics] gamma before the last update
     static constexpr size_t cnt = gpv + (size_t)kTopics * 8;                       // int32 [2][W * 64] counts of the words a lane finishes
-    static constexpr bool kGlobalCounts = (TL == 32 && TWL >= 4) || PYLDA_QUAD_FORCE_GCNT;
+    static constexpr bool kGlobalCounts = TWL >= 4 || PYLDA_QUAD_FORCE_GCNT;
     static constexpr size_t rows = (cnt + (kGlobalCounts ? 0 : (size_t)2 * W * 64 * 4) + 255) & ~(size_t)255;   // [16][TWL][kTopics]
     static constexpr size_t total = rows + (size_t)16 * TWL * kTopics * 8;
     static_assert(TL != 16 || 2 * total <= 160 * 1024, "K <= 128: two workgroups per CU");
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
 #pragma unroll
         for (int x = 0; x < NPIECE; ++x) h0[x] = mysrc[FL * x];
         const double cnt0 = count_of(0);
+        double s1 = 1.0, cnt1h = 0.0;
         if constexpr (C1 > 0) {
             double a1[R1 > 0 ? R1 : 1];
 #pragma unroll
@@ -310,13 +312,12 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
 #pragma unroll
             for (int x = 0; x < NPIECE; ++x) h1[x] = mysrc[FL * x];
             const double cnt1 = count_of(1);
-            // the reciprocal chain of the first chunk runs while the second transpose is in flight
+            // the reciprocal chain of the first chunk runs while the second transpose is in flight; the second
+            // chunk's chain is placed behind the first 32 FMAs of pass B (which need r0 only)
             if (live0 && !(s0 > 1e-280 && s0 < 1e300)) bad = 1;
             r0 = live0 ? cnt0 * rcp_newton(s0) : 0.0;
-            const double s1 = finish_sum(h1);
-            if (live1 && !(s1 > 1e-280 && s1 < 1e300)) bad = 1;
-            r1 = live1 ? cnt1 * rcp_newton(s1) : 0.0;
-            dpp_source_ready(r1);
+            s1 = finish_sum(h1);
+            cnt1h = cnt1;
         } else {
             const double s0 = finish_sum(h0);
             if (live0 && !(s0 > 1e-280 && s0 < 1e300)) bad = 1;
@@ -347,6 +348,12 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             constexpr int i = decltype(idx)::value + 1;
             row_bcast_fmac<2 * i>(q, r0, B[i]);
         });
+        if constexpr (C1 > 0) {
+            asm volatile("" : "+v"(s1));                                  // (keeps the chain below behind the FMAs above)
+            if (live1 && !(s1 > 1e-280 && s1 < 1e300)) bad = 1;
+            r1 = live1 ? cnt1h * rcp_newton(s1) : 0.0;
+            dpp_source_ready(r1);
+        }
         row_topic_sums(StaticIndex<0>());
         static_for<(C0 > 4 ? C0 - 4 : 0)>([&](auto idx) {
             constexpr int i = decltype(idx)::value + 4;
