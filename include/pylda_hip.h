@@ -176,7 +176,7 @@ int pylda_corpus_plan(pylda_corpus* corpus, int32_t capacity, int32_t* variant, 
  *                         safety-net kernel (the reference's formulation);
  *   "force_variant"  -1 (automatic) or a kernel variant index: 0..2 generic LDS 64/256/512
  *                    threads, 3 generic global, 4 slab, 6 quilt, 7 streaming, 8 hybrid, 9 wide
- *                    tiered, 10 quad (5 was round 1's column kernel, removed);
+ *                    tiered, 10 quad, 11 fused streaming (5 was round 1's column kernel, removed);
  *                    a variant that cannot take a document falls back to the automatic choice;
  *   "quad" (1: documents of <= 208 distinct terms at 64 < K <= 128 run as 4-wavefront workgroups, two
  *   per CU), "quilt_odd", "quilt12", "gather_rows"  A/B switches of kernel geometry

@@ -23,6 +23,7 @@
 #include "estep_slab.h"
 #include "estep_quilt.h"
 #include "estep_quad.h"
+#include "estep_qfuse.h"
 #include "estep_qstream.h"
 #include "estep_qhybrid.h"
 #include "estep_qwide.h"
@@ -48,7 +49,8 @@ enum Variant : int {
     kQstream = 7,       // tile streamed from L2 twice per iteration, quilt lanes (estep_qstream.h)
     kQhybrid = 8,       // tile split over registers / LDS / streamed remainder (estep_qhybrid.h)
     kQwide = 9,         // the same three tiers on a 2 x 32 lane grid with prefetched tail rows (estep_qwide.h)
-    kQuad = 10          // 4 wavefronts / document, two documents per CU, tile in registers + LDS rows (estep_quad.h)
+    kQuad = 10,         // 16 word groups / document, tile in registers + LDS rows (estep_quad.h)
+    kQfuse = 11         // table stride 512: rows streamed ONCE per iteration, normaliser and topic sums fused (estep_qfuse.h)
 };
 
 struct Launch {
@@ -280,6 +282,11 @@ int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
         *lds_bytes = 0;
         return kQuad;
     }
+    if ((ctx->force_variant < 0 || ctx->force_variant == kQfuse) && ctx->ldk == 512 && n <= 8 * kQfMaxSlots - 32 &&
+        ctx->lds_limit >= 160 * 1024) {
+        *lds_bytes = 0;
+        return kQfuse;
+    }
     if ((ctx->force_variant < 0 || ctx->force_variant == kQuilt) && quilt_geom_for(ctx, n).W > 0) {
         *lds_bytes = 0;
         return kQuilt;
@@ -468,6 +475,16 @@ int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     case 321004: return launch_quad<32, 10, 4>(ctx, p, L);
     }
     return fail(ctx, PYLDA_ERR_STATE, "no quad kernel for geometry %d", L.rn);
+}
+
+int launch_qfuse(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    auto kern = estep_qfuse_kernel<6, 2>;
+    const size_t lds = QfuseLds<2>::total;
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(512), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
 }
 
 template <int KRL>
@@ -824,7 +841,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kQuad || value == kRetired5)
+        if (value < -1 || value > kQfuse || value == kRetired5)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld is not a kernel variant", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
@@ -1116,6 +1133,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kQhybrid: rc = launch_qhybrid_any(ctx, p, L); break;
             case kQwide: rc = launch_qwide_any(ctx, p, L); break;
             case kQuad: rc = launch_quad_any(ctx, p, L); break;
+            case kQfuse: rc = launch_qfuse(ctx, p, L); break;
             default: rc = launch_generic<256, true>(ctx, p, L); break;
             }
             close_bracket(class_bracket, ctx->stream);

@@ -1,0 +1,351 @@
+// Fused streaming E-step kernel for 448 < K <= 512 (table stride 512; cfg 5: nips.88-05 at K = 500,
+// N_d ~ 230, tile 230 x 4 KiB = 920 KB - more than a CU holds).
+//
+// The two-pass streaming kernel (estep_qstream.h) re-reads the whole tile from L2 / Infinity Cache
+// twice per inner iteration; at K = 500 every CU streams 1.8 MB per document-iteration and the chip is
+// bound by the fabric (6.8 TB/s in aggregate, 95 % of wave-cycles waiting:
+// profiles/r02_nips_k500_qstream_rocprof_summary.txt).  Two observations cut that traffic ~3x:
+//
+//   * a word's normaliser needs only ITS row and t:  nrm_n = sum_k B[n][k] t[k],  r_n = c_n / nrm_n,
+//     so with all 512 topics of a row inside ONE wavefront (64 lanes x 8 values) normaliser and
+//     topic sums fuse:  row -> dot -> wavefront sum -> r -> q += r * row.  Each row is read ONCE per
+//     iteration, and the normaliser reduction is a wavefront-local DPP / permlane sum (no LDS
+//     transposes, no second pass).  The extra VALU work (one 64-lane reduction per word) is free
+//     here: the kernel waits for memory;
+//   * part of the tile stays on chip: the first RWL slots of every wavefront in VGPRs (8 x 8 = 64
+//     words, 128 VGPRs), the next TWL slots as whole rows in LDS (8 x 2 = 16 words, 64 KiB).
+//
+// Layout: 8 wavefronts per document, word n belongs to wavefront n % 8, slot n / 8; lane c holds
+// topics 2c + 128*jj + {0,1}, jj < 4, of a row (16-byte pieces 1 KiB apart).  Streamed rows go
+// through FOUR 16-VGPR buffers per wavefront, each requested four slots ahead by an asm statement and
+// handed over by its s_waitcnt vmcnt (the loop has no other vector-memory traffic), i.e. 128 KiB in
+// flight per CU.
+//
+// Cross-wavefront: per-wavefront topic partials in LDS -> barrier -> 512 topic threads (all eight
+// wavefronts): gamma update, exp(psi), fixed-point convergence sum (estep_quilt.h) -> barrier.
+#pragma once
+#include "estep_common.h"
+#include "special_device.h"
+
+namespace pylda {
+
+constexpr int kQfMaxSlots = 128;            // word slots per wavefront: documents up to 1024 distinct terms
+
+template <int TWL>
+struct QfuseLds {
+    static constexpr int W = 8;
+    static constexpr int kTopics = 512;
+    static constexpr size_t sp = 0;                                                // [W][kTopics] topic partials
+    static constexpr size_t tt = sp + (size_t)W * kTopics * 8;                     // [2][kTopics]
+    static constexpr size_t alf = tt + (size_t)2 * kTopics * 8;                    // [kTopics] alpha
+    static constexpr size_t gpv = alf + (size_t)kTopics * 8;                       // [kTopics] gamma before the last update
+    static constexpr size_t chg = gpv + (size_t)kTopics * 8;                       // u64[2]
+    static constexpr size_t misc = chg + 16;                                       // [8][W]
+    static constexpr size_t ids = misc + (size_t)8 * W * 8;                        // int [W][kQfMaxSlots]
+    static constexpr size_t cnt = ids + (size_t)W * kQfMaxSlots * 4;               // double [W][kQfMaxSlots]
+    static constexpr size_t rr = cnt + (size_t)W * kQfMaxSlots * 8;                // double [W][kQfMaxSlots]  r of the last iteration
+    static constexpr size_t rows = (rr + (size_t)W * kQfMaxSlots * 8 + 255) & ~(size_t)255;   // [W][TWL][kTopics]
+    static constexpr size_t total = rows + (size_t)W * TWL * kTopics * 8;
+    static_assert(total <= 160 * 1024, "fits the LDS");
+};
+
+struct GlobalRow {
+    f64x2 p[4];
+    __device__ __forceinline__ void unpack(double (&row)[8]) const
+    {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            row[2 * jj] = p[jj].x;
+            row[2 * jj + 1] = p[jj].y;
+        }
+    }
+};
+// the four 16-byte pieces (1 KiB apart) of a 4-KiB table row, requested now, usable after global_row_wait<N>
+__device__ __forceinline__ void global_row_request(GlobalRow& r, const void* ptr)
+{
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"
+                 : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
+                 : "v"(ptr)
+                 : "memory");
+}
+// NEWER: vector-memory loads issued after this row's (they may stay outstanding)
+template <int NEWER>
+__device__ __forceinline__ void global_row_wait(GlobalRow& r)
+{
+    static_assert(NEWER == 0 || NEWER == 4 || NEWER == 8 || NEWER == 12, "whole rows");
+    if constexpr (NEWER == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
+    else if constexpr (NEWER == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
+    else if constexpr (NEWER == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
+}
+
+template <int RWL, int TWL>
+__global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
+{
+    using L = QfuseLds<TWL>;
+    constexpr int W = 8, NT = 512, KT = 512, KRL = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sp = reinterpret_cast<double*>(smem + L::sp);
+    double* tt = reinterpret_cast<double*>(smem + L::tt);
+    double* alf = reinterpret_cast<double*>(smem + L::alf);
+    double* gpv = reinterpret_cast<double*>(smem + L::gpv);
+    unsigned long long* chg = reinterpret_cast<unsigned long long*>(smem + L::chg);
+    double* misc = reinterpret_cast<double*>(smem + L::misc);
+
+    const int tid = threadIdx.x;
+    const int c = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int K = p.K, ldk = p.ldk;
+    const int doc = p.order[blockIdx.x];
+    const int64_t lo = p.doc_ptr[doc];
+    const int N = (int)(p.doc_ptr[doc + 1] - lo);
+    const int S = (N + W - 1) / W;                          // word slots per wavefront: word n = slot * 8 + wave
+    constexpr int kOnChip = RWL + TWL;
+    const int NS = S > kOnChip ? (S - kOnChip + 3) & ~3 : 0;   // streamed slots, padded to whole trips of four
+    const int Spad = kOnChip + NS;
+    int* myids = reinterpret_cast<int*>(smem + L::ids) + wave * kQfMaxSlots;
+    double* mycnt = reinterpret_cast<double*>(smem + L::cnt) + wave * kQfMaxSlots;
+    double* myrr = reinterpret_cast<double*>(smem + L::rr) + wave * kQfMaxSlots;
+    double2* myrows = reinterpret_cast<double2*>(smem + L::rows) + (size_t)wave * TWL * (KT / 2) + c;
+    const double2* table = reinterpret_cast<const double2*>(p.expElog);
+    const int ldk2 = ldk / 2;
+
+    // ---- word ids / counts of this wavefront's slots, token total (:162) ----
+    double local = 0.0;
+    for (int s = c; s < Spad; s += kWave) {
+        const int n = s * W + wave;
+        const bool live = n < N;
+        myids[s] = live ? p.term_id[lo + n] : 0;            // dead slots: a valid row, count 0 => r = 0
+        const double ct = live ? (double)p.term_ct[lo + n] : 0.0;
+        mycnt[s] = ct;
+        myrr[s] = 0.0;
+        local += ct;
+    }
+    local = wave_sum(local);
+    double asum = 0.0;
+    for (int k = c; k < K; k += kWave) asum += p.alpha[k];
+    asum = wave_sum(asum);
+    const bool topic_live = tid < K;
+    alf[tid] = topic_live ? p.alpha[tid] : 1.0;
+    if (c == 0) misc[wave] = local;
+    if (tid == 0) chg[0] = chg[1] = 0ull;
+    __syncthreads();                                        // also: myids / mycnt are in place
+
+    // ---- on-chip tiers: registers, LDS rows ----
+    double B[RWL][KRL];
+#pragma unroll
+    for (int i = 0; i < RWL; ++i) {
+        const double2* row = table + (size_t)myids[i] * ldk2 + c;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const double2 v2 = row[64 * jj];
+            B[i][2 * jj] = v2.x;
+            B[i][2 * jj + 1] = v2.y;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TWL; ++t) {
+        const double2* row = table + (size_t)myids[RWL + t] * ldk2 + c;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) myrows[t * (KT / 2) + 64 * jj] = row[64 * jj];
+    }
+    double total = 0.0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) total += misc[w];
+    const double psi_total = uniform_f64(digamma(asum + total));
+    double gam = topic_live ? alf[tid] + total / K : 1.0;                 // :165 (padding topics never move)
+    tt[tid] = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
+    __syncthreads();                                        // t is published; the LDS rows are written (same wavefront reads them)
+
+    int it = 0;
+    int bad = 0;
+    ExpDigammaScalarCoef coef;
+    auto row_address = [&](int slot) { return (const void*)(table + (size_t)myids[slot] * ldk2 + c); };
+    while (it < p.max_iter) {                                             // :174
+        const int buf = it & 1;
+        double tq[KRL];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const double2 t2 = reinterpret_cast<const double2*>(tt + buf * KT)[c + 64 * jj];
+            tq[2 * jj] = t2.x;
+            tq[2 * jj + 1] = t2.y;
+        }
+        double q[KRL];
+#pragma unroll
+        for (int j = 0; j < KRL; ++j) q[j] = 0.0;
+        // one word, fused: normaliser (wavefront sum of the lanes' 8-topic dots), r, topic sums
+        auto word = [&](const double (&row)[8], int slot) {
+            const double cnt = mycnt[slot];
+            const double nrm = wave_sum(dot8(row, tq));
+            const bool live = cnt > 0.0;
+            if (live && !(nrm > 1e-280 && nrm < 1e300)) bad = 1;
+            const double r = live ? cnt * rcp_newton(nrm) : 0.0;
+            if (c == 0) myrr[slot] = r;
+#pragma unroll
+            for (int j = 0; j < KRL; ++j) q[j] = fma(r, row[j], q[j]);
+        };
+#pragma unroll
+        for (int i = 0; i < RWL; ++i) {
+            word(B[i], i);
+            if (i & 1) __builtin_amdgcn_sched_barrier(0);     // two words' chains side by side, not eight (registers)
+        }
+#pragma unroll
+        for (int t = 0; t < TWL; ++t) {
+            double row[8];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const double2 v2 = myrows[t * (KT / 2) + 64 * jj];
+                row[2 * jj] = v2.x;
+                row[2 * jj + 1] = v2.y;
+            }
+            word(row, RWL + t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (NS > 0) {
+            // (requested here, not before the on-chip words: with the buffers live across those the kernel
+            //  spills - and a spilled in-flight buffer would be stored before its data lands)
+            GlobalRow g0, g1, g2, g3;
+            global_row_request(g0, row_address(kOnChip + 0));
+            global_row_request(g1, row_address(kOnChip + 1));
+            global_row_request(g2, row_address(kOnChip + 2));
+            global_row_request(g3, row_address(kOnChip + 3));
+            int s = kOnChip;
+            double row[8];
+            for (; s + 4 < Spad; s += 4) {          // full trips: every buffer is re-requested four slots ahead
+                global_row_wait<12>(g0); g0.unpack(row); word(row, s + 0); global_row_request(g0, row_address(s + 4)); __builtin_amdgcn_sched_barrier(0);
+                global_row_wait<12>(g1); g1.unpack(row); word(row, s + 1); global_row_request(g1, row_address(s + 5)); __builtin_amdgcn_sched_barrier(0);
+                global_row_wait<12>(g2); g2.unpack(row); word(row, s + 2); global_row_request(g2, row_address(s + 6)); __builtin_amdgcn_sched_barrier(0);
+                global_row_wait<12>(g3); g3.unpack(row); word(row, s + 3); global_row_request(g3, row_address(s + 7)); __builtin_amdgcn_sched_barrier(0);
+            }
+            global_row_wait<12>(g0); g0.unpack(row); word(row, s + 0); __builtin_amdgcn_sched_barrier(0);    // last trip: the pipeline drains
+            global_row_wait<8>(g1); g1.unpack(row); word(row, s + 1); __builtin_amdgcn_sched_barrier(0);
+            global_row_wait<4>(g2); g2.unpack(row); word(row, s + 2); __builtin_amdgcn_sched_barrier(0);
+            global_row_wait<0>(g3); g3.unpack(row); word(row, s + 3);
+        }
+        // per-wavefront topic partials: lane c, register j  <->  topic 2c + 128*(j>>1) + (j&1)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            reinterpret_cast<double2*>(sp + (size_t)wave * KT)[c + 64 * jj] = double2{q[2 * jj], q[2 * jj + 1]};
+        __syncthreads();
+
+        // C. gamma update: one thread per topic
+        {
+            double part[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) part[w] = sp[w * KT + tid];
+            const double t_mine = tt[buf * KT + tid], alpha_k = alf[tid];
+            keep_together(part);
+            const double s0 = (part[0] + part[1]) + (part[4] + part[5]), s1 = (part[2] + part[3]) + (part[6] + part[7]);
+            const double gnew = fma(t_mine, s0 + s1, alpha_k);            // :185
+            const double diff = topic_live ? fabs(gnew - gam) : 0.0;      // :187
+            gpv[tid] = gam;
+            gam = gnew;                                                   // :188
+            atomicAdd(&chg[buf], change_fixed(diff));
+            coef.load();
+            tt[(buf ^ 1) * KT + tid] = topic_live ? exp_digamma_minus_with(gam, psi_total, coef) : 0.0;
+            if (tid == 0) chg[buf ^ 1] = 0ull;
+        }
+        ++it;
+        __syncthreads();
+        const double change = (double)chg[buf] * (1.0 / kChangeScale);
+        if (change <= p.tol * K) break;                                   // :189 (mean <= tol)
+    }
+    const int last = (it - 1) & 1;
+
+    bad = __syncthreads_or(bad);
+    if (bad) {
+        if (!p.heldout) {
+            for (int n = tid; n < N; n += NT) p.rfinal[lo + n] = 0.0;
+            p.tfinal[(size_t)doc * ldk + tid] = 0.0;
+        }
+        if (tid == 0) p.status[doc] = 1;
+        return;
+    }
+
+    // ---- document terms (:195-204) with the last phi = B t r (identities: estep_slab.h) ----
+    double term1 = 0.0;
+    if (p.heldout || p.want_doc_ll) {
+        double tq[KRL];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const double2 t2 = reinterpret_cast<const double2*>(tt + last * KT)[c + 64 * jj];
+            tq[2 * jj] = t2.x;
+            tq[2 * jj + 1] = t2.y;
+        }
+        const double2* gtable = reinterpret_cast<const double2*>(p.expElog_elog);
+        for (int s = 0; s < S; ++s) {
+            const double2* row = gtable + (size_t)myids[s] * ldk2 + c;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const double2 g2 = row[64 * jj];
+                a0 = fma(g2.x, tq[2 * jj], a0);
+                a1 = fma(g2.y, tq[2 * jj + 1], a1);
+            }
+            term1 = fma(myrr[s], a0 + a1, term1);          // r = 0 for dead slots; summed over the lanes below
+        }
+    }
+    double term3 = 0.0, shift_term = 0.0;
+    for (int s = c; s < S; s += kWave) {
+        const int n = s * W + wave;
+        if (n < N) {
+            const double cnt = mycnt[s], r = myrr[s];
+            term3 = fma(cnt, log(cnt) - log(r), term3);    // c_n log(normaliser_n), normaliser = c_n / r_n
+            if (p.heldout) shift_term = fma(cnt, p.shift[myids[s]], shift_term);
+            else p.rfinal[lo + n] = r;
+        }
+    }
+    double term2 = 0.0, lse_term = 0.0, lgam = 0.0, gsum = 0.0;
+    if (topic_live) {
+        const double t_last = tt[last * KT + tid];
+        const double mass = gam - alf[tid];
+        const double ltv = digamma(gpv[tid]) - psi_total;
+        term2 = ltv * mass;
+        if (p.heldout) lse_term = p.topic_lse[tid] * mass;
+        lgam = lgamma_pos(gam);
+        gsum = gam;
+        p.gamma[(size_t)doc * K + tid] = gam;
+        if (!p.heldout) p.tfinal[(size_t)doc * ldk + tid] = t_last;
+    } else if (!p.heldout) {
+        p.tfinal[(size_t)doc * ldk + tid] = 0.0;
+    }
+    term1 = wave_sum(term1);
+    term2 = wave_sum(term2);
+    lse_term = wave_sum(lse_term);
+    lgam = wave_sum(lgam);
+    gsum = wave_sum(gsum);
+    term3 = wave_sum(term3);
+    shift_term = wave_sum(shift_term);
+    __syncthreads();
+    if (c == 0) {
+        misc[0 * W + wave] = term1;
+        misc[1 * W + wave] = term2;
+        misc[2 * W + wave] = lse_term;
+        misc[3 * W + wave] = lgam;
+        misc[4 * W + wave] = gsum;
+        misc[5 * W + wave] = term3;
+        misc[6 * W + wave] = shift_term;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t1 = 0.0, t2 = 0.0, tl = 0.0, lg = 0.0, gs = 0.0, t3 = 0.0, sh = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            t1 += misc[0 * W + w];
+            t2 += misc[1 * W + w];
+            tl += misc[2 * W + w];
+            lg += misc[3 * W + w];
+            gs += misc[4 * W + w];
+            t3 += misc[5 * W + w];
+            sh += misc[6 * W + w];
+        }
+        const double ent = t1 + t2 - t3;
+        p.doc_ll[doc] = p.alpha_term + lg - lgamma_pos(gs) - ent;        // :195-199
+        p.doc_words_ll[doc] = p.heldout ? t1 + sh - tl : 0.0;            // :204
+        p.iters[doc] = it;
+        p.status[doc] = 0;
+    }
+}
+
+}  // namespace pylda

@@ -111,7 +111,7 @@ def test_ap_heldout_k10_matches_reference_goldens(capi, ap_test):
     assert abs(out["words_log_likelihood"] - float(g["corpus_words_ll"])) < 1e-9 * abs(float(g["corpus_words_ll"]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11])
 def test_every_kernel_variant_agrees(capi, ap_train, variant):
     g = ap_train
     docs = list(range(0, 2000, 10))
@@ -253,6 +253,38 @@ def test_wide_table_kernels_agree(capi, K, V, mean_len):
         again = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
         assert np.array_equal(out["gamma"], again["gamma"]) and np.array_equal(out["sstats"], again["sstats"])
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
+
+
+@pytest.mark.parametrize("K,V,mean_len", [(500, 1500, 230), (512, 1200, 60), (449, 1500, 700), (480, 1000, 100)])
+def test_fused_streaming_kernel_agrees(capi, K, V, mean_len):
+    """448 < K <= 512 (table stride 512): the fused single-pass streaming kernel (registers + LDS rows + four
+    row buffers in flight) against the C oracle, the two-pass streaming kernel and the generic kernel;
+    documents from a handful of terms (no streamed slots) to several hundred (many trips of the row pipeline)."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(K * 13 + mean_len)
+    ptr, ids, cts = random_corpus(rng, 28, V, mean_len, zipf=0.8)
+    eta = rng.gamma(100.0, 0.01, (K, V))
+    eta[:, rng.choice(V, V // 4, replace=False)] = 1.0 / V
+    alpha = rng.uniform(0.05, 1.5, K)
+    ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
+    gen = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 3)])
+    held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
+    for variant in (11, 7):
+        out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
+        check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
+        assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+        assert np.mean(out["iters"] == gen["iters"]) >= 0.95
+        held = run(capi, alpha, eta, ptr, ids, cts, heldout=True, options=[("force_variant", variant)])
+        check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"],
+                      ll_key="doc_words_ll", min_same=0.95)
+        again = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
+        assert np.array_equal(out["gamma"], again["gamma"]) and np.array_equal(out["sstats"], again["sstats"])
+        assert np.array_equal(out["doc_ll"], again["doc_ll"])
+    for mi, tol in [(1, 1e-6), (3, 1e-6), (50, 1e-2)]:
+        ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
+        out = run(capi, alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
+        assert np.array_equal(out["iters"], ref["iters"]), (mi, tol)
+        assert rel_err(out["gamma"], ref["gamma"]) < 1e-9
 
 
 @pytest.mark.parametrize("variant", [1, 3, 4, 6, 7, 8, 9, 10])
