@@ -282,7 +282,7 @@ int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
         *lds_bytes = 0;
         return kQuad;
     }
-    if ((ctx->force_variant < 0 || ctx->force_variant == kQfuse) && ctx->ldk == 512 && n <= 8 * kQfMaxSlots - 32 &&
+    if ((ctx->force_variant < 0 || ctx->force_variant == kQfuse) && (ctx->ldk == 384 || ctx->ldk == 512) && n <= 8 * kQfMaxSlots - 32 &&
         ctx->lds_limit >= 160 * 1024) {
         *lds_bytes = 0;
         return kQfuse;
@@ -477,14 +477,20 @@ int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     return fail(ctx, PYLDA_ERR_STATE, "no quad kernel for geometry %d", L.rn);
 }
 
-int launch_qfuse(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+template <int NP, int RWL, int TWL>
+int launch_qfuse_np(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
-    auto kern = estep_qfuse_kernel<6, 2>;
-    const size_t lds = QfuseLds<2>::total;
+    auto kern = estep_qfuse_kernel<NP, RWL, TWL>;
+    const size_t lds = QfuseLds<NP, TWL>::total;
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(512), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PYLDA_OK;
+}
+
+int launch_qfuse(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    return ctx->ldk == 512 ? launch_qfuse_np<4, 6, 2>(ctx, p, L) : launch_qfuse_np<3, 8, 3>(ctx, p, L);
 }
 
 template <int KRL>
@@ -735,7 +741,9 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     ctx->device = device;
     ctx->K = K;
     ctx->V = V;
-    ctx->ldk = K <= 16 ? 16 : K <= 32 ? 32 : (K + 63) / 64 * 64;
+    // table stride: K rounded up to 16 / 32 / a multiple of 64, above 256 to a multiple of 128 (the fused
+    // streaming kernel's rows are 64 lanes x 16-byte pieces)
+    ctx->ldk = K <= 16 ? 16 : K <= 32 ? 32 : K <= 256 ? (K + 63) / 64 * 64 : K <= 512 ? (K + 127) / 128 * 128 : (K + 63) / 64 * 64;
     auto bail = [&](int code) {
         g_create_error = ctx->err;
         pylda_destroy(ctx);

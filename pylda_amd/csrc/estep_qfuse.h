@@ -1,5 +1,5 @@
-// Fused streaming E-step kernel for 448 < K <= 512 (table stride 512; cfg 5: nips.88-05 at K = 500,
-// N_d ~ 230, tile 230 x 4 KiB = 920 KB - more than a CU holds).
+// Fused streaming E-step kernel for 256 < K <= 512 (table stride 384 or 512 = 128 * NP; cfg 5:
+// nips.88-05 at K = 500, N_d ~ 230, tile 230 x 4 KiB = 920 KB - more than a CU holds).
 //
 // The two-pass streaming kernel (estep_qstream.h) re-reads the whole tile from L2 / Infinity Cache
 // twice per inner iteration; at K = 500 every CU streams 1.8 MB per document-iteration and the chip is
@@ -31,10 +31,10 @@ namespace pylda {
 
 constexpr int kQfMaxSlots = 128;            // word slots per wavefront: documents up to 1024 distinct terms
 
-template <int TWL>
+template <int NP, int TWL>
 struct QfuseLds {
     static constexpr int W = 8;
-    static constexpr int kTopics = 512;
+    static constexpr int kTopics = 128 * NP;
     static constexpr size_t sp = 0;                                                // [W][kTopics] topic partials
     static constexpr size_t tt = sp + (size_t)W * kTopics * 8;                     // [2][kTopics]
     static constexpr size_t alf = tt + (size_t)2 * kTopics * 8;                    // [kTopics] alpha
@@ -49,19 +49,20 @@ struct QfuseLds {
     static_assert(total <= 160 * 1024, "fits the LDS");
 };
 
+template <int NP>
 struct GlobalRow {
-    f64x2 p[4];
-    __device__ __forceinline__ void unpack(double (&row)[8]) const
+    f64x2 p[NP];
+    __device__ __forceinline__ void unpack(double (&row)[2 * NP]) const
     {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < NP; ++jj) {
             row[2 * jj] = p[jj].x;
             row[2 * jj + 1] = p[jj].y;
         }
     }
 };
-// the four 16-byte pieces (1 KiB apart) of a 4-KiB table row, requested now, usable after global_row_wait<N>
-__device__ __forceinline__ void global_row_request(GlobalRow& r, const void* ptr)
+// the NP 16-byte pieces (1 KiB apart) of a table row, requested now, usable after global_row_wait<ROWS_NEWER>
+__device__ __forceinline__ void global_row_request(GlobalRow<4>& r, const void* ptr)
 {
     asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"
                  "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"
@@ -69,22 +70,49 @@ __device__ __forceinline__ void global_row_request(GlobalRow& r, const void* ptr
                  : "v"(ptr)
                  : "memory");
 }
-// NEWER: vector-memory loads issued after this row's (they may stay outstanding)
-template <int NEWER>
-__device__ __forceinline__ void global_row_wait(GlobalRow& r)
+__device__ __forceinline__ void global_row_request(GlobalRow<3>& r, const void* ptr)
 {
-    static_assert(NEWER == 0 || NEWER == 4 || NEWER == 8 || NEWER == 12, "whole rows");
-    if constexpr (NEWER == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
-    else if constexpr (NEWER == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
-    else if constexpr (NEWER == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
+    asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:1024\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:2048"
+                 : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2])
+                 : "v"(ptr)
+                 : "memory");
+}
+// ROWS_NEWER: rows requested after this one (their loads may stay outstanding)
+template <int ROWS_NEWER>
+__device__ __forceinline__ void global_row_wait(GlobalRow<4>& r)
+{
+    static_assert(ROWS_NEWER >= 0 && ROWS_NEWER <= 3, "four buffers");
+    if constexpr (ROWS_NEWER == 3) asm volatile("s_waitcnt vmcnt(12)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
+    else if constexpr (ROWS_NEWER == 2) asm volatile("s_waitcnt vmcnt(8)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
+    else if constexpr (ROWS_NEWER == 1) asm volatile("s_waitcnt vmcnt(4)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
 }
+template <int ROWS_NEWER>
+__device__ __forceinline__ void global_row_wait(GlobalRow<3>& r)
+{
+    static_assert(ROWS_NEWER >= 0 && ROWS_NEWER <= 3, "four buffers");
+    if constexpr (ROWS_NEWER == 3) asm volatile("s_waitcnt vmcnt(9)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]) : : "memory");
+    else if constexpr (ROWS_NEWER == 2) asm volatile("s_waitcnt vmcnt(6)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]) : : "memory");
+    else if constexpr (ROWS_NEWER == 1) asm volatile("s_waitcnt vmcnt(3)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]) : : "memory");
+}
 
-template <int RWL, int TWL>
+// sum_j row[j] * t[j] over a lane's values of one word
+__device__ __forceinline__ double lane_dot(const double (&row)[8], const double (&t)[8]) { return dot8(row, t); }
+__device__ __forceinline__ double lane_dot(const double (&row)[6], const double (&t)[6])
+{
+    const double a = fma(row[4], t[4], fma(row[2], t[2], row[0] * t[0]));
+    const double b = fma(row[5], t[5], fma(row[3], t[3], row[1] * t[1]));
+    return a + b;
+}
+
+template <int NP, int RWL, int TWL>
 __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
 {
-    using L = QfuseLds<TWL>;
-    constexpr int W = 8, NT = 512, KT = 512, KRL = 8;
+    using L = QfuseLds<NP, TWL>;
+    constexpr int W = 8, NT = 512, KT = 128 * NP, KRL = 2 * NP;
+    static_assert(NP == 3 || NP == 4, "table stride 384 or 512");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sp = reinterpret_cast<double*>(smem + L::sp);
     double* tt = reinterpret_cast<double*>(smem + L::tt);
@@ -126,8 +154,9 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     double asum = 0.0;
     for (int k = c; k < K; k += kWave) asum += p.alpha[k];
     asum = wave_sum(asum);
+    const bool topic_thread = tid < KT;
     const bool topic_live = tid < K;
-    alf[tid] = topic_live ? p.alpha[tid] : 1.0;
+    if (topic_thread) alf[tid] = topic_live ? p.alpha[tid] : 1.0;
     if (c == 0) misc[wave] = local;
     if (tid == 0) chg[0] = chg[1] = 0ull;
     __syncthreads();                                        // also: myids / mycnt are in place
@@ -138,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     for (int i = 0; i < RWL; ++i) {
         const double2* row = table + (size_t)myids[i] * ldk2 + c;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < NP; ++jj) {
             const double2 v2 = row[64 * jj];
             B[i][2 * jj] = v2.x;
             B[i][2 * jj + 1] = v2.y;
@@ -148,14 +177,17 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     for (int t = 0; t < TWL; ++t) {
         const double2* row = table + (size_t)myids[RWL + t] * ldk2 + c;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) myrows[t * (KT / 2) + 64 * jj] = row[64 * jj];
+        for (int jj = 0; jj < NP; ++jj) myrows[t * (KT / 2) + 64 * jj] = row[64 * jj];
     }
     double total = 0.0;
 #pragma unroll
     for (int w = 0; w < W; ++w) total += misc[w];
     const double psi_total = uniform_f64(digamma(asum + total));
-    double gam = topic_live ? alf[tid] + total / K : 1.0;                 // :165 (padding topics never move)
-    tt[tid] = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
+    double gam = 1.0;
+    if (topic_thread) {
+        gam = topic_live ? alf[tid] + total / K : 1.0;                    // :165 (padding topics never move)
+        tt[tid] = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
+    }
     __syncthreads();                                        // t is published; the LDS rows are written (same wavefront reads them)
 
     int it = 0;
@@ -166,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
         const int buf = it & 1;
         double tq[KRL];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < NP; ++jj) {
             const double2 t2 = reinterpret_cast<const double2*>(tt + buf * KT)[c + 64 * jj];
             tq[2 * jj] = t2.x;
             tq[2 * jj + 1] = t2.y;
@@ -175,9 +207,9 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
 #pragma unroll
         for (int j = 0; j < KRL; ++j) q[j] = 0.0;
         // one word, fused: normaliser (wavefront sum of the lanes' 8-topic dots), r, topic sums
-        auto word = [&](const double (&row)[8], int slot) {
+        auto word = [&](const double (&row)[KRL], int slot) {
             const double cnt = mycnt[slot];
-            const double nrm = wave_sum(dot8(row, tq));
+            const double nrm = wave_sum(lane_dot(row, tq));
             const bool live = cnt > 0.0;
             if (live && !(nrm > 1e-280 && nrm < 1e300)) bad = 1;
             const double r = live ? cnt * rcp_newton(nrm) : 0.0;
@@ -192,9 +224,9 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
         }
 #pragma unroll
         for (int t = 0; t < TWL; ++t) {
-            double row[8];
+            double row[KRL];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
+            for (int jj = 0; jj < NP; ++jj) {
                 const double2 v2 = myrows[t * (KT / 2) + 64 * jj];
                 row[2 * jj] = v2.x;
                 row[2 * jj + 1] = v2.y;
@@ -205,32 +237,32 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
         if (NS > 0) {
             // (requested here, not before the on-chip words: with the buffers live across those the kernel
             //  spills - and a spilled in-flight buffer would be stored before its data lands)
-            GlobalRow g0, g1, g2, g3;
+            GlobalRow<NP> g0, g1, g2, g3;
             global_row_request(g0, row_address(kOnChip + 0));
             global_row_request(g1, row_address(kOnChip + 1));
             global_row_request(g2, row_address(kOnChip + 2));
             global_row_request(g3, row_address(kOnChip + 3));
             int s = kOnChip;
-            double row[8];
+            double row[KRL];
             for (; s + 4 < Spad; s += 4) {          // full trips: every buffer is re-requested four slots ahead
-                global_row_wait<12>(g0); g0.unpack(row); word(row, s + 0); global_row_request(g0, row_address(s + 4)); __builtin_amdgcn_sched_barrier(0);
-                global_row_wait<12>(g1); g1.unpack(row); word(row, s + 1); global_row_request(g1, row_address(s + 5)); __builtin_amdgcn_sched_barrier(0);
-                global_row_wait<12>(g2); g2.unpack(row); word(row, s + 2); global_row_request(g2, row_address(s + 6)); __builtin_amdgcn_sched_barrier(0);
-                global_row_wait<12>(g3); g3.unpack(row); word(row, s + 3); global_row_request(g3, row_address(s + 7)); __builtin_amdgcn_sched_barrier(0);
+                global_row_wait<3>(g0); g0.unpack(row); word(row, s + 0); global_row_request(g0, row_address(s + 4)); __builtin_amdgcn_sched_barrier(0);
+                global_row_wait<3>(g1); g1.unpack(row); word(row, s + 1); global_row_request(g1, row_address(s + 5)); __builtin_amdgcn_sched_barrier(0);
+                global_row_wait<3>(g2); g2.unpack(row); word(row, s + 2); global_row_request(g2, row_address(s + 6)); __builtin_amdgcn_sched_barrier(0);
+                global_row_wait<3>(g3); g3.unpack(row); word(row, s + 3); global_row_request(g3, row_address(s + 7)); __builtin_amdgcn_sched_barrier(0);
             }
-            global_row_wait<12>(g0); g0.unpack(row); word(row, s + 0); __builtin_amdgcn_sched_barrier(0);    // last trip: the pipeline drains
-            global_row_wait<8>(g1); g1.unpack(row); word(row, s + 1); __builtin_amdgcn_sched_barrier(0);
-            global_row_wait<4>(g2); g2.unpack(row); word(row, s + 2); __builtin_amdgcn_sched_barrier(0);
+            global_row_wait<3>(g0); g0.unpack(row); word(row, s + 0); __builtin_amdgcn_sched_barrier(0);    // last trip: the pipeline drains
+            global_row_wait<2>(g1); g1.unpack(row); word(row, s + 1); __builtin_amdgcn_sched_barrier(0);
+            global_row_wait<1>(g2); g2.unpack(row); word(row, s + 2); __builtin_amdgcn_sched_barrier(0);
             global_row_wait<0>(g3); g3.unpack(row); word(row, s + 3);
         }
         // per-wavefront topic partials: lane c, register j  <->  topic 2c + 128*(j>>1) + (j&1)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < NP; ++jj)
             reinterpret_cast<double2*>(sp + (size_t)wave * KT)[c + 64 * jj] = double2{q[2 * jj], q[2 * jj + 1]};
         __syncthreads();
 
         // C. gamma update: one thread per topic
-        {
+        if (topic_thread) {
             double part[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) part[w] = sp[w * KT + tid];
@@ -257,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     if (bad) {
         if (!p.heldout) {
             for (int n = tid; n < N; n += NT) p.rfinal[lo + n] = 0.0;
-            p.tfinal[(size_t)doc * ldk + tid] = 0.0;
+            if (topic_thread) p.tfinal[(size_t)doc * ldk + tid] = 0.0;
         }
         if (tid == 0) p.status[doc] = 1;
         return;
@@ -268,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     if (p.heldout || p.want_doc_ll) {
         double tq[KRL];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < NP; ++jj) {
             const double2 t2 = reinterpret_cast<const double2*>(tt + last * KT)[c + 64 * jj];
             tq[2 * jj] = t2.x;
             tq[2 * jj + 1] = t2.y;
@@ -278,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
             const double2* row = gtable + (size_t)myids[s] * ldk2 + c;
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
+            for (int jj = 0; jj < NP; ++jj) {
                 const double2 g2 = row[64 * jj];
                 a0 = fma(g2.x, tq[2 * jj], a0);
                 a1 = fma(g2.y, tq[2 * jj + 1], a1);
@@ -307,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
         gsum = gam;
         p.gamma[(size_t)doc * K + tid] = gam;
         if (!p.heldout) p.tfinal[(size_t)doc * ldk + tid] = t_last;
-    } else if (!p.heldout) {
+    } else if (topic_thread && !p.heldout) {
         p.tfinal[(size_t)doc * ldk + tid] = 0.0;
     }
     term1 = wave_sum(term1);

@@ -255,9 +255,10 @@ def test_wide_table_kernels_agree(capi, K, V, mean_len):
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
 
 
-@pytest.mark.parametrize("K,V,mean_len", [(500, 1500, 230), (512, 1200, 60), (449, 1500, 700), (480, 1000, 100)])
+@pytest.mark.parametrize("K,V,mean_len", [(500, 1500, 230), (512, 1200, 60), (449, 1500, 700), (480, 1000, 100),
+                                          (300, 1500, 210), (384, 1200, 90), (257, 1500, 500), (385, 900, 150)])
 def test_fused_streaming_kernel_agrees(capi, K, V, mean_len):
-    """448 < K <= 512 (table stride 512): the fused single-pass streaming kernel (registers + LDS rows + four
+    """256 < K <= 512 (table stride 384 / 512): the fused single-pass streaming kernel (registers + LDS rows + four
     row buffers in flight) against the C oracle, the two-pass streaming kernel and the generic kernel;
     documents from a handful of terms (no streamed slots) to several hundred (many trips of the row pipeline)."""
     from oracle import c_oracle
