@@ -139,6 +139,25 @@ void* pylda_gamma_device(pylda_corpus* corpus);
  * (e.g. after an all-reduce); -1 leaves a flag unchanged. */
 int pylda_mark_device_state(pylda_ctx* ctx, int have_eta, int have_sstats);
 
+/* Multi-GPU exchange without Python (documents shard across GPUs, ONE all-reduce of the
+ * K x V sufficient statistics per outer iteration).  RCCL is bound at run time (dlopen of librccl.so;
+ * PYLDA_RCCL_PATH overrides the search), so the library has no link-time dependency on it.
+ *   rank 0:      pylda_comm_unique_id(id)        128 opaque bytes; the host hands them to every rank
+ *                                                (MPI, a socket, a file)
+ *   every rank:  pylda_comm_init(ctx, id, rank, world_size)      collective
+ *   per outer iteration, between pylda_estep and pylda_mstep:
+ *                pylda_allreduce_sstats(ctx)     in-place sum of the V x ldk device buffer, enqueued on the
+ *                                                context's stream (ordered with the kernels, no host sync)
+ *                pylda_allreduce_doubles(ctx, v, n)   sum of a short host vector (document log-likelihood,
+ *                                                #documents, alpha statistics: variational_bayes.py:232-233)
+ * Every rank then runs the identical pylda_mstep.  The Python class does the same through torch.distributed. */
+#define PYLDA_COMM_ID_BYTES 128
+int pylda_comm_unique_id(void* id_out);
+int pylda_comm_init(pylda_ctx* ctx, const void* id, int rank, int world_size);
+int pylda_comm_destroy(pylda_ctx* ctx);
+int pylda_allreduce_sstats(pylda_ctx* ctx);
+int pylda_allreduce_doubles(pylda_ctx* ctx, double* values, int64_t n);
+
 /* Device M-step (variational_bayes.py:218-235) on the resident buffers:
  * topic log-likelihood from the PRE-update eta (:222-224), eta <- sstats +
  * beta (:226), alpha sufficient statistics from the gamma of `corpus`

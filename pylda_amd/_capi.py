@@ -48,6 +48,11 @@ SIGNATURES = {
     "pylda_eta_device": (_vp, [_vp]),
     "pylda_gamma_device": (_vp, [_vp]),
     "pylda_mark_device_state": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "pylda_comm_unique_id": (ctypes.c_int, [_vp]),
+    "pylda_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "pylda_comm_destroy": (ctypes.c_int, [_vp]),
+    "pylda_allreduce_sstats": (ctypes.c_int, [_vp]),
+    "pylda_allreduce_doubles": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int64]),
     "pylda_mstep": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, _c_double_p]),
     "pylda_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pylda_kernel_time": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_int64_p]),
@@ -162,6 +167,16 @@ def parse_corpus(lines, vocabulary, lowercase=False):
     if rc != 0:
         raise PyldaError(rc, "pylda_parse_corpus")
     return doc_ptr, term_id[:nnz.value], term_ct[:nnz.value], len(lines) - n_docs.value
+
+
+def comm_unique_id():
+    """128 opaque bytes naming a new RCCL communicator (call on rank 0, hand to every rank)."""
+    lib = load()
+    buf = ctypes.create_string_buffer(128)
+    rc = lib.pylda_comm_unique_id(ctypes.cast(buf, _vp))
+    if rc != 0:
+        raise PyldaError(rc, (lib.pylda_last_error(None) or b"").decode())
+    return buf.raw
 
 
 def device_count():
@@ -302,6 +317,22 @@ class Context(object):
 
     def mark_device_state(self, have_eta=-1, have_sstats=-1):
         self._check(self._lib.pylda_mark_device_state(self._h, int(have_eta), int(have_sstats)))
+
+    # ---- multi-GPU exchange through the C ABI (RCCL bound at run time; no torch involved) ----
+    def comm_init(self, unique_id, rank, world_size):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._lib.pylda_comm_init(self._h, ctypes.cast(buf, _vp), int(rank), int(world_size)))
+
+    def comm_destroy(self):
+        self._check(self._lib.pylda_comm_destroy(self._h))
+
+    def allreduce_sstats(self):
+        self._check(self._lib.pylda_allreduce_sstats(self._h))
+
+    def allreduce_doubles(self, values):
+        values = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._check(self._lib.pylda_allreduce_doubles(self._h, _dp(values), values.size))
+        return values
 
     # ---- profiling ----
     def set_profiling(self, enabled):

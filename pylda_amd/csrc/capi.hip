@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "comm.h"
 #include "estep_common.h"
 #include "estep_generic.h"
 #include "estep_logspace.h"
@@ -99,6 +100,10 @@ struct pylda_ctx {
     double beta_sum = 0.0, beta_lgamma_sum = 0.0;
 
     std::vector<double> h_alpha;
+    void* comm = nullptr;           // RCCL communicator of pylda_comm_init (multi-GPU through the C ABI)
+    int comm_world = 1;
+    double* d_comm_small = nullptr; // staging buffer of pylda_allreduce_doubles
+    size_t comm_small_cap = 0;
     bool have_eta = false, have_alpha = false, have_sstats = false;
     int force_logspace = 0;
     int force_variant = -1;
@@ -801,6 +806,8 @@ void pylda_destroy(pylda_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->comm) pylda::comm_destroy(ctx->comm);
+    dev_free(ctx->d_comm_small);
     drain_events(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     dev_free(ctx->d_eta); dev_free(ctx->d_elog); dev_free(ctx->d_expElog); dev_free(ctx->d_expElog_elog); dev_free(ctx->d_sstats);
@@ -1362,6 +1369,74 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* t
     double ll = K * (std::lgamma(bsum) - blg);                                                                      // :222
     for (int k = 0; k < K; ++k) ll += per_topic[k];
     if (topic_log_likelihood) *topic_log_likelihood = ll;
+    return PYLDA_OK;
+}
+
+int pylda_comm_unique_id(void* id_out)
+{
+    if (!id_out) return fail(nullptr, PYLDA_ERR_INVALID, "comm_unique_id: NULL");
+    std::string err;
+    const int rc = pylda::comm_unique_id(id_out, &err);
+    return rc == PYLDA_OK ? rc : fail(nullptr, rc, "comm_unique_id: %s", err.c_str());
+}
+
+int pylda_comm_init(pylda_ctx* ctx, const void* id, int rank, int world_size)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!id || world_size < 1 || rank < 0 || rank >= world_size)
+        return fail(ctx, PYLDA_ERR_INVALID, "comm_init: rank %d of %d", rank, world_size);
+    if (ctx->comm) return fail(ctx, PYLDA_ERR_STATE, "comm_init: the context already has a communicator");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    const int rc = pylda::comm_init(&ctx->comm, id, rank, world_size, &err);
+    if (rc != PYLDA_OK) return fail(ctx, rc, "comm_init: %s", err.c_str());
+    ctx->comm_world = world_size;
+    return PYLDA_OK;
+}
+
+int pylda_comm_destroy(pylda_ctx* ctx)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->comm) pylda::comm_destroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_world = 1;
+    return PYLDA_OK;
+}
+
+int pylda_allreduce_sstats(pylda_ctx* ctx)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!ctx->comm) return fail(ctx, PYLDA_ERR_STATE, "allreduce_sstats: pylda_comm_init has not been called");
+    if (!ctx->have_sstats) return fail(ctx, PYLDA_ERR_STATE, "allreduce_sstats: no training-mode E-step has run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    // on the context's stream: ordered behind the E-step's kernels and before the M-step's
+    const int rc = pylda::comm_allreduce_sum_f64(ctx->comm, ctx->d_sstats, (size_t)ctx->V * ctx->ldk, ctx->stream, &err);
+    return rc == PYLDA_OK ? rc : fail(ctx, rc, "allreduce_sstats: %s", err.c_str());
+}
+
+int pylda_allreduce_doubles(pylda_ctx* ctx, double* values, int64_t n)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!ctx->comm) return fail(ctx, PYLDA_ERR_STATE, "allreduce_doubles: pylda_comm_init has not been called");
+    if (n < 0 || (n > 0 && !values)) return fail(ctx, PYLDA_ERR_INVALID, "allreduce_doubles: bad argument");
+    if (n == 0) return PYLDA_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm_small_cap < (size_t)n) {
+        dev_free(ctx->d_comm_small);
+        ctx->comm_small_cap = 0;
+        const int rc = dev_alloc(ctx, &ctx->d_comm_small, (size_t)n);
+        if (rc != PYLDA_OK) return rc;
+        ctx->comm_small_cap = (size_t)n;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_comm_small, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    std::string err;
+    const int rc = pylda::comm_allreduce_sum_f64(ctx->comm, ctx->d_comm_small, (size_t)n, ctx->stream, &err);
+    if (rc != PYLDA_OK) return fail(ctx, rc, "allreduce_doubles: %s", err.c_str());
+    HIP_TRY(ctx, hipMemcpyAsync(values, ctx->d_comm_small, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PYLDA_OK;
 }
 

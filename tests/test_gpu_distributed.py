@@ -151,3 +151,38 @@ def test_bench_launches_its_own_ranks(tmp_path):
     sub = rec["synth1m"]
     assert sub["n_gpus"] == 2 and sub["scaling"] == "strong" and sub["config"]["docs_total"] == 4000
     assert sum(c["documents"] for c in sub["roofline"]["launch_classes"]) == sub["config"]["docs_per_gpu"]
+
+
+def test_c_abi_allreduce_world_of_one(ap_train):
+    """The multi-GPU entry points of the C ABI (RCCL bound at run time, no torch.distributed): a one-rank
+    communicator reduces the library's own device buffer in place - an identity - on the context's stream,
+    between E-step and M-step, and the short host vector likewise; call-order errors are reported."""
+    from pylda_amd import _capi
+    g = ap_train
+    ptr = g["doc_ptr"][:301]
+    ctx = _capi.Context(10, 6806)
+    corpus = ctx.corpus(ptr, g["term_id"][:ptr[-1]], g["term_ct"][:ptr[-1]])
+    ctx.set_alpha(g["alpha"])
+    ctx.set_eta(g["eta"])
+    with pytest.raises(_capi.PyldaError) as e:
+        ctx.allreduce_sstats()                              # no communicator yet
+    assert e.value.status == -4
+    uid = _capi.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 0, 1)
+    with pytest.raises(_capi.PyldaError):
+        ctx.allreduce_sstats()                              # no training E-step yet
+    ctx.estep(corpus)
+    before = ctx.get_sstats()
+    ctx.allreduce_sstats()
+    assert np.array_equal(ctx.get_sstats(), before)
+    ll = ctx.estep_results(corpus)[0]
+    vec = ctx.allreduce_doubles(np.concatenate([[ll, 300.0], np.arange(10.0)]))
+    assert vec[0] == ll and vec[1] == 300.0 and np.array_equal(vec[2:], np.arange(10.0))
+    tll, ass = ctx.mstep(corpus, g["beta"])                 # the M-step after the exchange, same stream
+    assert np.isfinite(tll) and ass.shape == (10,)
+    with pytest.raises(_capi.PyldaError):
+        ctx.comm_init(uid, 0, 1)                            # one communicator per context
+    ctx.comm_destroy()
+    corpus.close()
+    ctx.close()
