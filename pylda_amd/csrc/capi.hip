@@ -1500,7 +1500,7 @@ __global__ void special_test_kernel(const double* x, int64_t n, double* dg, doub
 __global__ void expdigamma_test_kernel(const double* x, int64_t n, double c, double* out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = pylda::exp_digamma_minus(x[i], c);
+    if (i < n) out[i] = c > 1e3 ? pylda::exp_digamma_minus_levels(x[i], c - 2e3) : pylda::exp_digamma_minus(x[i], c);
 }
 }  // namespace
 

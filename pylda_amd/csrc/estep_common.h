@@ -384,6 +384,16 @@ __device__ __forceinline__ unsigned long long change_fixed(double diff, double b
     return (unsigned long long)__double_as_longlong(biased) & 0x000fffffffffffffull;
 }
 
+// *p = hi << 32, with the constant created HERE: a copy hoisted out of the inner loop of a kernel at the
+// register limit is spilled to scratch and reloaded on the serial path (seen: scratch_load + vmcnt(0)
+// in front of a one-lane LDS store).
+__device__ __forceinline__ void store_u64_hi(unsigned long long* p, unsigned hi)
+{
+    unsigned lo = 0;
+    asm volatile("" : "+v"(hi), "+v"(lo));
+    *p = ((unsigned long long)hi << 32) | lo;
+}
+
 // Forces the N values to be live in registers at this point (loads that produce them are all
 // issued before it; the scheduler otherwise recycles two registers and serialises the round trips).
 template <int N>

@@ -192,7 +192,6 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
 
     int it = 0;
     int bad = 0;
-    ExpDigammaScalarCoef coef;
     auto row_address = [&](int slot) { return (const void*)(table + (size_t)myids[slot] * ldk2 + c); };
     while (it < p.max_iter) {                                             // :174
         const int buf = it & 1;
@@ -274,9 +273,9 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
             gpv[tid] = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
-            coef.load();
-            tt[(buf ^ 1) * KT + tid] = topic_live ? exp_digamma_minus_with(gam, psi_total, coef) : 0.0;
-            if (tid == 0) chg[buf ^ 1] = 0ull;
+            const double t_next = exp_digamma_minus_levels(gam, psi_total)   /* (tables fetched in place: no scalar registers to spare across pass B) */;
+            tt[(buf ^ 1) * KT + tid] = topic_live ? t_next : 0.0;
+            if (tid == 0) store_u64_hi(&chg[buf ^ 1], 0u);
         }
         ++it;
         __syncthreads();

@@ -46,6 +46,24 @@ namespace pylda {
 #ifndef PYLDA_QUAD_FORCE_GCNT
 #define PYLDA_QUAD_FORCE_GCNT 0
 #endif
+// Development builds only (tools/phase_stamps_quad.py): s_memtime stamps around the phases of the inner
+// loop, summed per wavefront and written over the document's gamma row.  The stamps drain the LDS queue,
+// so absolute times are 10-15 % high; the split between the phases is what counts.
+#ifndef PYLDA_QUAD_STAMPS
+#define PYLDA_QUAD_STAMPS 0
+#endif
+#if PYLDA_QUAD_STAMPS
+#define QUAD_STAMP(j)                                                          \
+    do {                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
+        const long long now_ = __builtin_amdgcn_s_memtime();                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
+        stamp_acc[j] += now_ - stamp_prev;                                     \
+        stamp_prev = now_;                                                     \
+    } while (0)
+#else
+#define QUAD_STAMP(j) do { } while (0)
+#endif
 
 template <int TL, int RWL, int TWL>
 struct QuadLds {
@@ -106,6 +124,11 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     double* gpv = reinterpret_cast<double*>(smem + L::gpv);
     int* cntv = reinterpret_cast<int*>(smem + L::cnt);
 
+#if PYLDA_QUAD_STAMPS
+    long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_prev = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -153,9 +176,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
     double asum = 0.0;
     for (int k = lane; k < K; k += kWave) asum += p.alpha[k];
-    const bool topic_thread = tid < KT;
-    const bool topic_live = tid < K;
-    if (topic_thread) alf[tid] = topic_live ? p.alpha[tid] : 1.0;
+    if (tid < KT) alf[tid] = tid < K ? p.alpha[tid] : 1.0;
 
     // ---- the tile gather: register slots, then the LDS slots (through registers) ----
     double B[RWL][KRL];
@@ -195,6 +216,13 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     if (lane == 0) misc[wave] = local;
     if (tid == 0) chg[0] = chg[1] = 0ull;
     lds_only_barrier();
+    // the gamma phase: one thread per topic on the first KT / 64 wavefronts.  (Measured and not adopted: taking
+    // the two documents' gamma wavefronts on disjoint SIMD pairs - HW_ID / LDS_ALLOC tell a workgroup where it
+    // sits - and s_setprio around the phase: both within noise, the phase is bound by its dependent chain.)
+    const int trank = wave < KT / kWave ? wave : -1;
+    const bool topic_thread = trank >= 0;
+    const int ktid = topic_thread ? trank * kWave + lane : 0;      // the topic this thread owns in the gamma phase
+    const bool topic_live = topic_thread && ktid < K;
     double total = 0.0;
 #pragma unroll
     for (int w = 0; w < W; ++w) total += misc[w];
@@ -203,8 +231,8 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     // ---- gamma phase state: thread k < KT owns topic k ----
     double gam = 1.0;
     if (topic_thread) {
-        gam = topic_live ? alf[tid] + total / K : 1.0;                    // :165 (padding topics never move)
-        tt[tid] = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
+        gam = topic_live ? alf[ktid] + total / K : 1.0;                   // :165 (padding topics never move)
+        tt[ktid] = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
     }
     lds_only_barrier();
 
@@ -239,10 +267,10 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     }
 #pragma unroll
     for (int j = 0; j < KRL; ++j) asm volatile("" : "+v"(tq[j]));
-    ExpDigammaScalarCoef coef;
     LdsRow rowbuf;
     auto request_row = [&](int t) { lds_row_request<TL * 16>(rowbuf, myrows + t * (KT / 2)); };
     if constexpr (TWL > 0) request_row(0);
+    QUAD_STAMP(8);                                                        // prologue: gather, first t
     for (;;) {                                                            // :174
         const int buf = it & 1;
 
@@ -281,6 +309,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         }
 #pragma unroll
         for (int i = 0; i < C0; ++i) myred[i * RS + cw] = PRE ? lane_group_sum<2>(a[i]) : a[i];
+        QUAD_STAMP(0);                                                    // t wait + pass A over slots 0-7 (+ rows 0, 1) + writes
         if (moved <= thresh || left <= 0) {                               // :189 (mean <= tol), :174
             if constexpr (TWL > 2) lds_row_wait(rowbuf);                  // no read may land after the loop (row 2 is in flight)
             break;
@@ -300,6 +329,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             if constexpr (TWL > 0) request_row(0);                        // for pass B
             double s0 = finish_sum(h0);
             asm volatile("" : "+v"(s0));                                  // h0 is dead from here on
+            QUAD_STAMP(1);                                                // slots 8.., rows 2, 3, first transpose landed and summed
             wave_lds_exchange();                                          // the writes below stay behind the reads above
             if constexpr (PRE && R1 > 0) asm volatile("s_nop 1" : "+v"(a1[R1 - 1]));       // (as above: dot8's last add)
             if constexpr (PRE && TWL > 0) asm volatile("s_nop 1" : "+v"(pr[TWL - 1]));
@@ -325,6 +355,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         }
 
         dpp_source_ready(r0);
+        QUAD_STAMP(2);                                                    // second transpose, first reciprocal chain
 
         // B. q[k] over this lane's words (registers and LDS rows interleaved), then over the word groups
         double q[KRL];
@@ -387,15 +418,26 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
                 mysp[2 * c + (j & 1) + 2 * TL * (j >> 1)] = v;
             }
         }
+        QUAD_STAMP(3);                                                    // pass B + swaps + partials written
+        // both coefficient tables of exp_digamma_minus_levels, requested ahead of the barrier: the scalar-cache
+        // round trips (150-200 ticks each when taken inside the phase) ride on the barrier wait
+        ExpDigammaLevelsA coef_a;
+        ExpDigammaLevelsB coef_b;
+        if (topic_thread) {
+            coef_a.load();
+            coef_b.load();
+        }
         __syncthreads();
+        QUAD_STAMP(4);                                                    // barrier 1
 
         // C. gamma update by the topic threads
         if (topic_thread) {
             double part_sum[W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) part_sum[w] = red[(size_t)w * (L::red_wave / 8) + tid];
-            const double t_mine = tt[buf * KT + tid], alpha_k = alf[tid];
+            for (int w = 0; w < W; ++w) part_sum[w] = red[(size_t)w * (L::red_wave / 8) + ktid];
+            const double t_mine = tt[buf * KT + ktid], alpha_k = alf[ktid];
             keep_together(part_sum);
+            QUAD_STAMP(5);                                                // partial sums arrived
             double s0 = part_sum[0] + part_sum[1], s1 = part_sum[2] + part_sum[3];
             if constexpr (W == 8) {
                 s0 += part_sum[4] + part_sum[5];
@@ -403,16 +445,18 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             }
             const double gnew = fma(t_mine, s0 + s1, alpha_k);            // :185
             const double diff = fabs(gnew - gam);                         // :187
-            gpv[tid] = gam;
+            gpv[ktid] = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
-            coef.load();
-            tt[(buf ^ 1) * KT + tid] = topic_live ? exp_digamma_minus_with(gam, psi_total, coef) : 0.0;
-            if (tid == 0) chg[buf ^ 1] = 0ull;
+            const double t_next = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
+            tt[(buf ^ 1) * KT + ktid] = topic_live ? t_next : 0.0;
+            if (ktid == 0) store_u64_hi(&chg[buf ^ 1], 0u);
         }
         ++it;
         --left;
+        QUAD_STAMP(6);                                                    // gamma phase
         __syncthreads();
+        QUAD_STAMP(7);                                                    // barrier 2
         moved = (long long)chg[buf];
 #pragma unroll
         for (int jj = 0; jj < KRL / 2; ++jj) {
@@ -422,6 +466,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         }
     }
     const int last = (it - 1) & 1;          // tt[last] holds t of the last executed iteration
+    QUAD_STAMP(9);                                                        // the half iteration behind the last update
 
     bad = __syncthreads_or(bad);
     if (bad) {
@@ -475,18 +520,31 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     }
     double term2 = 0.0, lse_term = 0.0, lgam = 0.0, gsum = 0.0;
     if (topic_live) {
-        const double t_last = tt[last * KT + tid], alpha_k = alf[tid];
+        const double t_last = tt[last * KT + ktid], alpha_k = alf[ktid];
         const double mass = gam - alpha_k;                                // = t_last * s
-        const double ltv = digamma(gpv[tid]) - psi_total;                 // log t of the last iteration
+        const double ltv = digamma(gpv[ktid]) - psi_total;                // log t of the last iteration
         term2 = ltv * mass;
-        if (p.heldout) lse_term = p.topic_lse[tid] * mass;
+        if (p.heldout) lse_term = p.topic_lse[ktid] * mass;
         lgam = lgamma_pos(gam);
         gsum = gam;
-        p.gamma[(size_t)doc * K + tid] = gam;
-        if (!p.heldout) p.tfinal[(size_t)doc * ldk + tid] = t_last;
+        if (!PYLDA_QUAD_STAMPS) p.gamma[(size_t)doc * K + ktid] = gam;
+        if (!p.heldout) p.tfinal[(size_t)doc * ldk + ktid] = t_last;
     } else if (topic_thread && !p.heldout) {
-        p.tfinal[(size_t)doc * ldk + tid] = 0.0;
+        p.tfinal[(size_t)doc * ldk + ktid] = 0.0;
     }
+#if PYLDA_QUAD_STAMPS
+    QUAD_STAMP(10);                                                       // epilogue up to the reductions
+    if (lane == 0) {
+        unsigned hw_id, lds_alloc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc));
+        double* dbg = p.gamma + (size_t)doc * K + wave * 16;              // (needs K >= 16 * wavefronts)
+        for (int j = 0; j < 11; ++j) dbg[j] = (double)stamp_acc[j];
+        dbg[11] = (double)it;
+        dbg[12] = (double)hw_id;
+        dbg[13] = (double)lds_alloc;
+    }
+#endif
     term1 = wave_sum(term1);
     term2 = wave_sum(term2);
     lse_term = wave_sum(lse_term);

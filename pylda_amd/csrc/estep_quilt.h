@@ -159,10 +159,6 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
 #pragma unroll
     for (int j = 0; j < KRL; ++j) asm volatile("" : "+v"(tq[j]));   // (keeps the in-loop reads at the loop's end: the
                                                                      //  optimiser would merge both sets at the loop head)
-    ExpDigammaCoef coef;
-    coef.load();
-    double bias52 = 4503599627370496.0;
-    asm volatile("" : "+v"(bias52));
     for (;;) {                                                            // :174
         const int buf = it & 1;
 
@@ -204,6 +200,13 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             const int slot = m + (g & 1) * QV + (g >> 1) * (KRL / 2);      // register index j of the topic
             sp[wave * KT + 2 * c + (slot & 1) + 32 * (slot >> 1)] = v;
         }
+        // both coefficient tables of exp_digamma_minus_levels, requested ahead of the barrier (estep_quad.h)
+        ExpDigammaLevelsA coef_a;
+        ExpDigammaLevelsB coef_b;
+        if (topic_thread) {
+            coef_a.load();
+            coef_b.load();
+        }
         __syncthreads();
 
         // C. gamma update by the topic threads
@@ -222,10 +225,11 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
             const double diff = fabs(gnew - gam);                         // :187
             gam_prev = gam;
             gam = gnew;                                                   // :188
-            atomicAdd(&chg[buf], change_fixed(diff, bias52));
-            t_mine = topic_live ? exp_digamma_minus_with(gam, psi_total, coef) : 0.0;
+            atomicAdd(&chg[buf], change_fixed(diff));
+            const double t_next = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
+            t_mine = topic_live ? t_next : 0.0;
             tt[(buf ^ 1) * KT + tid] = t_mine;
-            if (tid == 0) chg[buf ^ 1] = 0ull;
+            if (tid == 0) store_u64_hi(&chg[buf ^ 1], 0u);
         }
         ++it;
         --left;

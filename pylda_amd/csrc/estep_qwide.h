@@ -386,10 +386,9 @@ __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, in
             gprevS[tid] = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
-            ExpDigammaScalarCoef coef;                                    // scalar registers, fetched here: no
-            coef.load();                                                  // vector registers to spare in this kernel
-            tt[(buf ^ 1) * KT + tid] = topic_live ? exp_digamma_minus_with(gam, psi_total, coef) : 0.0;
-            if (tid == 0) chg[buf ^ 1] = 0ull;
+            const double t_next = exp_digamma_minus_levels(gam, psi_total)   /* (tables fetched in place: no scalar registers to spare across pass B) */;
+            tt[(buf ^ 1) * KT + tid] = topic_live ? t_next : 0.0;
+            if (tid == 0) store_u64_hi(&chg[buf ^ 1], 0u);
         }
         ++it;
         --left;

@@ -226,6 +226,190 @@ struct ExpDigammaScalarCoef {
     }
 };
 
+// ---- exp(psi(x) - c), ordered level by level --------------------------------------------------
+// The gamma phase of the register kernels is ONE dependent chain per thread, run by a lone
+// wavefront per SIMD while the document's other wavefronts wait at a barrier: tools/valu_bench.hip
+// puts a dependent fp64 instruction 12.8 ticks behind its producer, an independent one 4.9.  hipcc
+// schedules these kernels for register pressure and ran the ~140 instructions of
+// exp_digamma_minus_with at ~10 ticks each (s_memtime stamps: 1400-1470 ticks per gamma phase).
+// This form fixes the order by hand instead: the instructions of one dependency LEVEL are written
+// together and a scheduling barrier keeps the levels apart, so two or three independent chains are
+// always in flight (recurrence shift | asymptotic series, then the even | odd halves of the exp
+// polynomial).  It is also shorter:
+//   * always y = x + 10 (the recurrence holds for every x > 0; the compare/select pairs go), with the
+//     shift polynomials evaluated at min(x, 1e25) so that they stay finite (beyond that the shift is
+//     < 1e-24 and drops out of the sum);
+//   * every FMA takes at most ONE scalar constant (VOP3 reads one SGPR pair): Horner chains on the even
+//     and odd coefficients instead of Estrin pairs, no v_mov of constants into accumulators;
+//   * the two coefficient tables sit in scalar registers one after the other (the second is fetched
+//     while the first half computes), 34 + 28 SGPRs, never more than 42 at a time.
+// 63 VALU instructions, 30 levels.  Pinned to scipy like the other forms
+// (tests/test_gpu_estep.py::test_device_fused_exp_digamma).
+__constant__ double kExpDigammaLevelsA[16] = {
+    10.0, 1e25, 9.0, 60.0, 1308.0, 12176.0, 40320.0, 240.0, 3924.0, 24352.0,
+    1.0 / 12.0, -1.0 / 120.0, 1.0 / 252.0, -1.0 / 240.0, 1.0 / 132.0, -691.0 / 32760.0};
+__constant__ double kExpDigammaLevelsB[14] = {
+    1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
+    1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0,
+    1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0, 1.0 / 6227020800.0};
+
+// d = a * b + s  /  d = a * s + v  /  d = min(a, s), exactly these VOP3 encodings (s: scalar register pair)
+__device__ __forceinline__ double fma_vvs(double a, double b, double s)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(s));
+    return d;
+}
+__device__ __forceinline__ double min_vs(double a, double s)
+{
+    double d;
+    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(s));
+    return d;
+}
+__device__ __forceinline__ double mov_s(double s)
+{
+    double d;
+    asm("v_mov_b64_e32 %0, %1" : "=v"(d) : "s"(s));
+    return d;
+}
+
+#define PYLDA_LEVEL() __builtin_amdgcn_sched_barrier(0)
+
+// the first table (the recurrence shift and the asymptotic series): fetched by the caller ahead of the
+// barrier in front of the gamma phase, so that the scalar-cache round trip is not on the chain
+struct ExpDigammaLevelsA {
+    double ten, big, nine, d3, d2, d1, d0, n3, n2, n1, b1, b2, b3, b4, b5, b6;
+    __device__ __forceinline__ void load()
+    {
+        typedef const double __attribute__((address_space(4)))* const_table_ptr;
+        const_table_ptr t = (const_table_ptr)kExpDigammaLevelsA;
+        asm volatile("" : "+s"(t));
+        ten = t[0], big = t[1], nine = t[2], d3 = t[3], d2 = t[4], d1 = t[5], d0 = t[6], n3 = t[7], n2 = t[8], n1 = t[9];
+        b1 = t[10], b2 = t[11], b3 = t[12], b4 = t[13], b5 = t[14], b6 = t[15];
+    }
+};
+
+// the second table (exp): fetched inside exp_digamma_minus_levels while the first half computes (PRELOADED
+// false: its scalar registers are then the first table's), or by the caller together with the first one
+struct ExpDigammaLevelsB {
+    double log2e, nln2hi, nln2lo, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13;
+    __device__ __forceinline__ void load()
+    {
+        typedef const double __attribute__((address_space(4)))* const_table_ptr;
+        const_table_ptr t = (const_table_ptr)kExpDigammaLevelsB;
+        asm volatile("" : "+s"(t));
+        log2e = t[0], nln2hi = t[1], nln2lo = t[2];
+        c3 = t[3], c4 = t[4], c5 = t[5], c6 = t[6], c7 = t[7], c8 = t[8], c9 = t[9], c10 = t[10], c11 = t[11], c12 = t[12], c13 = t[13];
+    }
+};
+
+template <bool PRELOADED = false>
+__device__ __forceinline__ double exp_digamma_minus_levels(double x, double c, const ExpDigammaLevelsA& k,
+                                                           const ExpDigammaLevelsB* kb_in = nullptr)
+{
+    const double ten = k.ten, big = k.big, nine = k.nine, d3 = k.d3, d2 = k.d2, d1 = k.d1, d0 = k.d0;
+    const double n3 = k.n3, n2 = k.n2, n1 = k.n1, b1 = k.b1, b2 = k.b2, b3 = k.b3, b4 = k.b4, b5 = k.b5, b6 = k.b6;
+    PYLDA_LEVEL();
+    const double y = x + ten;                                   // 1
+    const double xs = min_vs(x, big);
+    const double vb5 = mov_s(b5);
+    PYLDA_LEVEL();
+    double inv = __builtin_amdgcn_rcp(y);                       // 2
+    const double xs9 = xs + nine;
+    const double vb4 = mov_s(b4);
+    PYLDA_LEVEL();
+    const double P = xs * xs9;                                  // 3
+    double e = fma(-y, inv, 1.0);
+    const double tx = xs + xs9;                                 //    2x + 9
+    PYLDA_LEVEL();
+    double den = P + d3;                                        // 4
+    double num = P + n3;                                        //    D'(P) = 5 P^4 + 240 P^3 + ... : 5 P + 240 = 4 P + (P + 240)
+    inv = fma(inv, e, inv);
+    PYLDA_LEVEL();
+    den = fma_vvs(den, P, d2);                                  // 5
+    num = fma(P, 4.0, num);
+    e = fma(-y, inv, 1.0);
+    PYLDA_LEVEL();
+    den = fma_vvs(den, P, d1);                                  // 6
+    num = fma_vvs(num, P, n2);
+    inv = fma(inv, e, inv);
+    PYLDA_LEVEL();
+    den = fma_vvs(den, P, d0);                                  // 7
+    num = fma_vvs(num, P, n1);
+    const double w = inv * inv;
+    PYLDA_LEVEL();
+    den = den * P;                                              // 8
+    num = fma_vvs(num, P, d0);
+    const double w2 = w * w;
+    ExpDigammaLevelsB kb;
+    if constexpr (PRELOADED) kb = *kb_in;
+    else kb.load();
+    const double log2e = kb.log2e, nln2hi = kb.nln2hi, nln2lo = kb.nln2lo;
+    const double c3 = kb.c3, c4 = kb.c4, c5 = kb.c5, c6 = kb.c6, c7 = kb.c7, c8 = kb.c8, c9 = kb.c9, c10 = kb.c10, c11 = kb.c11,
+                 c12 = kb.c12, c13 = kb.c13;
+    PYLDA_LEVEL();
+    double rd = __builtin_amdgcn_rcp(den);                      // 9
+    double se = fma_scalar_mul(w2, b1, vb5);                    //    (B14 / 14 = B2 / 2 = 1/12)
+    double so = fma_scalar_mul(w2, b6, vb4);
+    PYLDA_LEVEL();
+    double f = fma(-den, rd, 1.0);                              // 10
+    se = fma_vvs(se, w2, b3);
+    so = fma_vvs(so, w2, b2);
+    PYLDA_LEVEL();
+    rd = fma(rd, f, rd);                                        // 11
+    se = fma_vvs(se, w2, b1);
+    const double nt = num * tx;
+    PYLDA_LEVEL();
+    f = fma(-den, rd, 1.0);                                     // 12
+    double ser = fma(so, w, se);
+    PYLDA_LEVEL();
+    rd = fma(rd, f, rd);                                        // 13
+    ser = ser * w;
+    const double vc10 = mov_s(c10);
+    PYLDA_LEVEL();
+    double tail = fma(inv, -0.5, -ser);                         // 14   psi(y) - log y
+    const double vc11 = mov_s(c11);
+    PYLDA_LEVEL();
+    tail = tail - c;                                            // 15
+    PYLDA_LEVEL();
+    tail = fma(-nt, rd, tail);                                  // 16   psi(x) - log y - c
+    PYLDA_LEVEL();
+    const double kx = tail * log2e;                             // 17
+    PYLDA_LEVEL();
+    const double kf = __builtin_rint(kx);                       // 18
+    PYLDA_LEVEL();
+    double r = fma_scalar_mul(kf, nln2hi, tail);                // 19
+    const int ki = (int)kf;
+    PYLDA_LEVEL();
+    r = fma_scalar_mul(kf, nln2lo, r);                          // 20
+    PYLDA_LEVEL();
+    const double r2 = r * r;                                    // 21
+    PYLDA_LEVEL();
+    double pe = fma_scalar_mul(r2, c12, vc10);                  // 22
+    double po = fma_scalar_mul(r2, c13, vc11);
+    PYLDA_LEVEL();
+    pe = fma_vvs(pe, r2, c8);                                   // 23
+    po = fma_vvs(po, r2, c9);
+    PYLDA_LEVEL();
+    pe = fma_vvs(pe, r2, c6);                                   // 24
+    po = fma_vvs(po, r2, c7);
+    PYLDA_LEVEL();
+    pe = fma_vvs(pe, r2, c4);                                   // 25
+    po = fma_vvs(po, r2, c5);
+    PYLDA_LEVEL();
+    pe = fma(pe, r2, 0.5);                                      // 26
+    po = fma_vvs(po, r2, c3);
+    PYLDA_LEVEL();
+    pe = fma(pe, r2, 1.0);                                      // 27
+    po = fma(po, r2, 1.0);
+    PYLDA_LEVEL();
+    double res = fma(po, r, pe);                                // 28
+    PYLDA_LEVEL();
+    res = ldexp(res, ki);                                       // 29
+    PYLDA_LEVEL();
+    return y * res;                                             // 30
+}
+
 struct ExpDigammaLiterals {
     __device__ __forceinline__ double exp_of(double x) const { return exp_shallow(x); }
     static constexpr double nine = 9.0, ten = 10.0;
@@ -234,6 +418,13 @@ struct ExpDigammaLiterals {
     static constexpr double b1 = 1.0 / 12.0, b2 = -1.0 / 120.0, b3 = 1.0 / 252.0, b4 = -1.0 / 240.0, b5 = 1.0 / 132.0,
                             b6 = -691.0 / 32760.0;
 };
+
+__device__ __forceinline__ double exp_digamma_minus_levels(double x, double c)
+{
+    ExpDigammaLevelsA k;
+    k.load();
+    return exp_digamma_minus_levels(x, c, k);
+}
 
 __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 {

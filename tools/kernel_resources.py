@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Registers / scratch per kernel from `hipcc -S --cuda-device-only` output: python tools/kernel_resources.py capi.s [filter]"""
+import re, subprocess, sys
+lines = open(sys.argv[1]).read().splitlines()
+flt = sys.argv[2] if len(sys.argv) > 2 else "estep"
+name, info = None, {}
+for l in lines:
+    m = re.match(r'^(_Z\w+):', l)
+    if m:
+        name = m.group(1)
+    for key in ('TotalNumSgprs', 'NumVgprs', 'ScratchSize', 'Occupancy'):
+        m2 = re.match(r'^; %s: (\d+)' % key, l)
+        if m2 and name:
+            info.setdefault(name, {})[key] = int(m2.group(1))
+for k, v in info.items():
+    if flt in k:
+        d = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip()
+        print("%-64s sgpr %3d vgpr %3d scratch %4d occupancy %d" % (d[:64], v.get('TotalNumSgprs', -1), v.get('NumVgprs', -1), v.get('ScratchSize', -1), v.get('Occupancy', -1)))
+
+# spill traffic inside loops: scratch_* / v_readlane / v_writelane in blocks the assembler comments mark as
+# "in Loop" or "Loop Header", per kernel and loop depth
+print()
+name, depth, spills = None, 0, {}
+for l in lines:
+    m = re.match(r'^(_Z\w+):', l)
+    if m:
+        name, depth = m.group(1), 0
+        continue
+    s = l.strip()
+    if s.startswith('.LBB') or s.startswith('; %bb.'):
+        m = re.search(r'(?:in Loop: Header=\S+|Loop Header:) Depth=(\d+)', l)
+        depth = int(m.group(1)) if m else 0
+        continue
+    if name and depth > 0 and flt in name and re.match(r'(scratch_|v_readlane|v_writelane)', s):
+        key = (name, depth, s.split()[0])
+        spills[key] = spills.get(key, 0) + 1
+for (k, depth, op), n in sorted(spills.items()):
+    d = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip()
+    print("IN LOOP depth %d: %-56s %-22s x %d" % (depth, d[:56], op, n))
