@@ -24,6 +24,7 @@
 #include "estep_slab.h"
 #include "estep_quilt.h"
 #include "estep_quad.h"
+#include "doc_terms.h"
 #include "estep_qfuse.h"
 #include "estep_qstream.h"
 #include "estep_qhybrid.h"
@@ -1159,6 +1160,9 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         }
         join();
     }
+    // the document terms the register kernels left out on the training fast path (status 3; doc_terms.h)
+    if (!heldout && !p.want_doc_ll && c->D > 0)
+        hipLaunchKernelGGL(doc_terms_kernel, dim3((unsigned)((c->D + 3) / 4)), dim3(256), 0, ctx->stream, p, c->D);
     close_bracket(doc_bracket, ctx->stream);
     if (ctx->profiling) ctx->estep_calls += 1;
 

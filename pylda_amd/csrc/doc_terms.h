@@ -1,0 +1,53 @@
+// Document terms of the likelihood (variational_bayes.py:195-199) for the documents whose E-step kernel left
+// them out (status 3), as a pass of its own.
+//
+// The register kernels hold a CU's whole register file per document (or half of it): their epilogue - K
+// lgamma, K + 2 N_d logarithms on a handful of active wavefronts, ~8000 cycles - costs the same slot time as
+// one and a half inner iterations while the tile registers sit idle.  On the training fast path (corpus-level
+// likelihood only, EstepParams::want_doc_ll == 0) everything the epilogue needs is in memory anyway for the
+// statistics pass: gamma, t of the last iteration (tfinal) and r_n = c_n / normaliser_n (rfinal).  Here one
+// wavefront per document recomputes the terms from those at full occupancy (cfg 3: 0.1 ms against 0.65 ms
+// inside the document kernels).
+//
+//   doc_ll[d] = alpha_term + sum_k lnG(gamma_k) - lnG(sum_k gamma_k)
+//               - ( sum_k log t_k (gamma_k - alpha_k) - sum_n c_n (log c_n - log r_n) )
+// (the remaining term of :199, sum_n c_n sum_k phi log B, comes once per corpus from the statistics pass;
+// log t_k = psi(gamma_k before the last update) - psi(sum gamma) is taken from the stored t_k.)
+#pragma once
+#include "estep_common.h"
+#include "special_device.h"
+
+namespace pylda {
+
+__global__ __launch_bounds__(256) void doc_terms_kernel(EstepParams p, int64_t D)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t doc = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+    if (doc >= D || p.status[doc] != 3) return;
+    const int K = p.K;
+    const double* gamma = p.gamma + (size_t)doc * K;
+    const double* t = p.tfinal + (size_t)doc * p.ldk;
+    double lgam = 0.0, gsum = 0.0, term2 = 0.0, term3 = 0.0;
+    for (int k = lane; k < K; k += kWave) {
+        const double g = gamma[k], mass = g - p.alpha[k];                 // = t_k * sum_n r_n B[w_n][k]
+        lgam += lgamma_pos(g);
+        gsum += g;
+        if (mass != 0.0) term2 = fma(log(t[k]), mass, term2);             // (t_k may have underflowed where the mass did)
+    }
+    const int64_t lo = p.doc_ptr[doc], hi = p.doc_ptr[doc + 1];
+    for (int64_t n = lo + lane; n < hi; n += kWave) {
+        const double c = (double)p.term_ct[n];
+        term3 = fma(c, log(c) - log(p.rfinal[n]), term3);                 // c_n log(normaliser_n)
+    }
+    lgam = wave_sum(lgam);
+    gsum = wave_sum(gsum);
+    term2 = wave_sum(term2);
+    term3 = wave_sum(term3);
+    if (lane == 0) {
+        p.doc_ll[doc] = p.alpha_term + lgam - lgamma_pos(gsum) - (term2 - term3);
+        p.doc_words_ll[doc] = 0.0;
+        p.status[doc] = 0;
+    }
+}
+
+}  // namespace pylda

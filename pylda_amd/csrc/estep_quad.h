@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     int* cntv = reinterpret_cast<int*>(smem + L::cnt);
 
 #if PYLDA_QUAD_STAMPS
-    long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long stamp_prev = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -448,7 +448,9 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             gpv[ktid] = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
+            QUAD_STAMP(11);                                               // gamma update, change into the fixed-point sum
             const double t_next = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
+            QUAD_STAMP(12);                                               // exp(psi(gamma) - psi(sum))
             tt[(buf ^ 1) * KT + ktid] = topic_live ? t_next : 0.0;
             if (ktid == 0) store_u64_hi(&chg[buf ^ 1], 0u);
         }
@@ -475,6 +477,22 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             for (int k = tid; k < ldk; k += NT) p.tfinal[(size_t)doc * ldk + k] = 0.0;
         }
         if (tid == 0) p.status[doc] = 1;
+        return;
+    }
+
+    // ---- training fast path: the document terms are left to doc_terms_kernel (doc_terms.h), which recomputes
+    //      them from gamma, t and r at full occupancy instead of on this workgroup's handful of wavefronts ----
+    if (!p.heldout && !p.want_doc_ll && !PYLDA_QUAD_STAMPS) {
+        if (live0 && part == 0) p.rfinal[lo + word0] = r0;
+        if (live1 && part == 0) p.rfinal[lo + word1] = r1;
+        if (topic_thread) {
+            if (topic_live) p.gamma[(size_t)doc * K + ktid] = gam;
+            p.tfinal[(size_t)doc * ldk + ktid] = topic_live ? tt[last * KT + ktid] : 0.0;
+        }
+        if (tid == 0) {
+            p.iters[doc] = it;
+            p.status[doc] = 3;
+        }
         return;
     }
 
@@ -543,6 +561,8 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         dbg[11] = (double)it;
         dbg[12] = (double)hw_id;
         dbg[13] = (double)lds_alloc;
+        dbg[14] = (double)stamp_acc[11];
+        dbg[15] = (double)stamp_acc[12];
     }
 #endif
     term1 = wave_sum(term1);

@@ -45,7 +45,8 @@ g = ctx.get_gamma(corpus)
 W = 4 if K <= 128 else 8
 print(cfg, "documents", len(sel), "classes", [(c["kernel"], c["geometry"], c["documents"]) for c in corpus.plan()], "opts", opts)
 names = ["t wait + A slots 0-7 (+rows)", "A slots 8.. + transpose 1", "transpose 2, reciprocals", "B FMA + swaps + write", "barrier 1",
-         "C: partials read", "C: compute", "barrier 2"]
+         "C: partials read", "C: t stored, LDS drained", "barrier 2"]
+sub = [(14, "C: gamma update + atomic done"), (15, "C: exp(psi(gamma) - c)")]
 for w in (0, W - 1):
     base = 16 * w
     its = g[:, base + 11]
@@ -53,6 +54,11 @@ for w in (0, W - 1):
     print("wavefront %d: mean iterations %.2f" % (w, its[ok].mean()))
     tot = 0
     for j, nm in enumerate(names):
+        if j == 6:
+            for k, nm2 in sub:
+                v = (g[ok, base + k] / its[ok]).mean()
+                tot += v
+                print("   %-30s %8.1f" % (nm2, v))
         v = (g[ok, base + j] / its[ok]).mean()
         tot += v
         print("   %-30s %8.1f" % (nm, v))
