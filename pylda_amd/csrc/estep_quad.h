@@ -132,6 +132,15 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    // Stride 256: wavefronts w and w + 4 of the document share a SIMD and, being in the same phase, would
+    // fight for issue slots in the FMA bursts and then wait for the LDS together.  With the first four at a
+    // higher priority a SIMD runs one wavefront's burst at full rate while the other one's LDS round trips
+    // are in flight (measured on the 193-208-term class of cfg 4: 466 -> 440 ns per document; priority 1, 2
+    // or 3, or raising the other four instead, all within 1.5 % of each other).  At stride 128 the two
+    // wavefronts of a SIMD belong to different documents, already out of phase: no gain there.
+    if constexpr (TL == 32) {
+        if (wave < 4) __builtin_amdgcn_s_setprio(2);
+    }
     const int g = lane / TL, c = lane % TL;
     const int cl = lane & 15;               // position inside the 16-lane row
     const int half = (lane >> 4) & (TL / 16 - 1);   // row of a 32-lane group
