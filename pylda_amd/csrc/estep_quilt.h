@@ -254,6 +254,20 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
         return;
     }
 
+    // ---- training fast path: the document terms are left to doc_terms_kernel (doc_terms.h; see estep_quad.h) ----
+    if (!p.heldout && !p.want_doc_ll) {
+        if (word_live && (c % LPW) == 0) p.rfinal[lo + my_word] = r_mine;
+        if (topic_thread) {
+            if (topic_live) p.gamma[(size_t)doc * K + tid] = gam;
+            p.tfinal[(size_t)doc * ldk + tid] = topic_live ? tt[last * KT + tid] : 0.0;
+        }
+        if (tid == 0) {
+            p.iters[doc] = it;
+            p.status[doc] = 3;
+        }
+        return;
+    }
+
     // ---- document terms (:195-204) with the last phi = B t r (see estep_slab.h) ----
 #pragma unroll
     for (int jj = 0; jj < KRL / 2; ++jj) {

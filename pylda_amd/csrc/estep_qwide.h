@@ -413,6 +413,21 @@ __global__ __launch_bounds__(kWave* W) void estep_qwide_kernel(EstepParams p, in
         return;
     }
 
+    // ---- training fast path: the document terms are left to doc_terms_kernel (doc_terms.h; see estep_quad.h) ----
+    if (!p.heldout && !p.want_doc_ll) {
+        if (word_live && my_part == 0) p.rfinal[lo + my_word] = r_mine;
+        for (int i = lane; i < nmineT; i += kWave) p.rfinal[lo + nbT + i] = myrrT[i];
+        if (topic_thread) {
+            if (topic_live) p.gamma[(size_t)doc * K + tid] = gam;
+            p.tfinal[(size_t)doc * ldk + tid] = topic_live ? tt[last * KT + tid] : 0.0;
+        }
+        if (tid == 0) {
+            p.iters[doc] = it;
+            p.status[doc] = 3;
+        }
+        return;
+    }
+
     // ---- document terms (:195-204) with the last phi = B t r (identities: estep_slab.h) ----
     double term1 = 0.0;
     if (p.heldout || p.want_doc_ll) {

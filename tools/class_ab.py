@@ -13,6 +13,9 @@ sel = np.nonzero((n >= nmin) & (n <= nmax))[0]
 newptr = np.concatenate([[0], np.cumsum(n[sel])]).astype(np.int64)
 idx = np.concatenate([np.arange(ptr[d], ptr[d + 1]) for d in sel]) if len(sel) < 300000 else None
 ids2, cts2 = ids[idx], cts[idx]
+import os
+if os.environ.get("CLASS_AB_VMOD"):      # probe: fold the vocabulary so that the table rows stay in L2 (timing only)
+    ids2 = (ids2 % int(os.environ["CLASS_AB_VMOD"])).astype(ids2.dtype)
 np.random.seed(0)
 eta = np.random.gamma(100., 0.01, (K, V))
 ctx = _capi.Context(K, V)
@@ -25,7 +28,7 @@ for _ in range(2):
     ctx.estep(corpus)
 ctx.synchronize()
 ctx.set_profiling(True); ctx.kernel_time(); corpus.plan()
-for _ in range(5):
+for _ in range(int(os.environ.get("CLASS_AB_STEPS", "5"))):      # (long runs: sustained clocks)
     ctx.estep(corpus)
 ctx.synchronize()
 doc_ms, ss_ms, calls = ctx.kernel_time()

@@ -18,6 +18,12 @@ __global__ __launch_bounds__(256) void bench(double* out, long long* ticks, doub
     double x = x0 + 1e-3 * threadIdx.x;
     const double c = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(c0)), __builtin_amdgcn_readfirstlane(__double2loint(c0)));
     double acc = 0.0;
+    ExpDigammaLevelsA ka;
+    ExpDigammaLevelsB kb;
+    if constexpr (FORM == 3) {          // both coefficient tables resident (the kernels request them ahead of a barrier)
+        ka.load();
+        kb.load();
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const long long t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -29,10 +35,12 @@ __global__ __launch_bounds__(256) void bench(double* out, long long* ticks, doub
             t = exp_digamma_minus_with(x, c, k);
         } else if constexpr (FORM == 1) {
             t = exp_digamma_minus(x, c);
-        } else {
+        } else if constexpr (FORM == 2) {
             ExpDigammaLevelsA k;
             k.load();
             t = exp_digamma_minus_levels(x, c, k);
+        } else {
+            t = exp_digamma_minus_levels<true>(x, c, ka, &kb);
         }
         acc += t;
         x = fma(t, 3.0, 0.25);      // the next argument depends on the result, as gamma' = alpha + t * s does
@@ -73,8 +81,10 @@ int main()
 {
     run<0>("exp_digamma_minus_with (scalar table)", 1);
     run<1>("exp_digamma_minus (literals)", 1);
-    run<2>("exp_digamma_minus_levels", 1);
+    run<2>("exp_digamma_minus_levels (tables fetched in place)", 1);
+    run<3>("exp_digamma_minus_levels (tables resident)", 1);
     run<0>("exp_digamma_minus_with (scalar table)", 2);
-    run<2>("exp_digamma_minus_levels", 2);
+    run<2>("exp_digamma_minus_levels (tables fetched in place)", 2);
+    run<3>("exp_digamma_minus_levels (tables resident)", 2);
     return 0;
 }
