@@ -273,12 +273,14 @@ class VariationalBayes(Inferencer):
         if group is not None:
             from pylda_amd import distributed
             distributed.allreduce_sstats(ctx, group)
-        document_log_likelihood, _, _ = ctx.estep_results(corpus)
         self._gamma_host_stale = self._gamma_on_device = True
         clock_e_step = time.time() - clock_e_step
 
         clock_m_step = time.time()
+        # the M-step kernels are queued behind the E-step before anything is read back: one wait per
+        # outer iteration instead of two (the likelihood scalars of the E-step are not touched by it)
         topic_log_likelihood, alpha_sufficient_statistics = ctx.mstep(corpus, self._alpha_beta)
+        document_log_likelihood, _, _ = ctx.estep_results(corpus)
         self._eta_device_newer = True
         number_of_documents = self._number_of_documents
         if group is not None:

@@ -326,6 +326,39 @@ def test_training_fast_path_corpus_likelihood(capi, ap_train, variant):
         ctx.close()
 
 
+@pytest.mark.parametrize("K,alpha0", [(100, 6e-4), (256, 6e-4), (400, 0.3), (128, 0.02)])
+def test_document_terms_pass_with_underflowing_topics(capi, ap_train, K, alpha0):
+    """Training fast path: the register kernels leave variational_bayes.py:195-199 to doc_terms_kernel, which
+    rebuilds log t_k from the stored t_k.  With alpha ~ 6e-4 the topics a document does not use end at
+    t_k = exp(psi(alpha) - psi(sum gamma)) = 0 and gamma_k - alpha_k = 0 exactly: their term must drop out,
+    not turn into 0 * log 0.  (K = 400: the fused streaming kernel's exit.)"""
+    g = ap_train
+    rng = np.random.default_rng(K)
+    ptr = g["doc_ptr"][:201]
+    tid, tct = g["term_id"][:ptr[-1]], g["term_ct"][:ptr[-1]]
+    eta = rng.gamma(100.0, 0.01, (K, 6806))
+    eta[rng.choice(K, K // 2, replace=False)] *= 1e-3          # topics nobody wants
+    alpha = np.full(K, alpha0)
+    ctx = capi.Context(K, 6806)
+    corpus = ctx.corpus(ptr, tid, tct)
+    ctx.set_alpha(alpha)
+    ctx.set_eta(eta)
+    ctx.set_option("doc_values", 1)
+    ctx.estep(corpus)
+    full_ll, _, nlog = ctx.estep_results(corpus)
+    gamma_full = ctx.get_gamma(corpus)
+    ctx.set_option("doc_values", 0)
+    ctx.estep(corpus)
+    fast_ll, _, nlog_fast = ctx.estep_results(corpus)
+    print("K=%d alpha=%g: kernels %s, %d documents through the log-space safety net, topics at gamma == alpha: %d"
+          % (K, alpha0, sorted({c["kernel"] for c in corpus.plan()}), nlog, int((gamma_full == alpha0).sum())))
+    assert np.isfinite(fast_ll) and nlog == nlog_fast
+    assert abs(fast_ll - full_ll) < 1e-11 * abs(full_ll)
+    assert np.array_equal(ctx.get_gamma(corpus), gamma_full)
+    corpus.close()
+    ctx.close()
+
+
 def test_nips_k500_matches_reference_goldens(capi):
     """BASELINE.json cfg 5 in miniature (parsed/nips.88-05, K=500, documents up to 482 distinct terms,
     goldens from the reference itself): exercises the streaming large-K kernel."""
