@@ -202,3 +202,20 @@ def test_hybrid_corpus_generator_is_the_numpy_generator():
     s = C.synthetic_lda_shard(900, 300, 300, 900, 7, 40, seed=11, chunk=300, device="cpu", workers=2)
     assert np.array_equal(s[1], a[1][a[0][300]:]) and np.array_equal(s[0], a[0][300:] - a[0][300])
     assert C.corpus_checksum(*a) == [900, int(a[0][-1]), int(a[1].astype(np.int64).sum()), int(a[2].sum())]
+
+
+def test_bench_all_cores_cpu_leg_runs_workers_and_adds_rates():
+    """bench.py's optional all-cores CPU figure: single-threaded oracle processes side by side, stragglers killed."""
+    import bench
+    rng = np.random.default_rng(0)
+    K, V, D = 8, 120, 80
+    ptr, ids, cts = [0], [], []
+    for _ in range(D):
+        u, c = np.unique(rng.choice(V, size=20), return_counts=True)
+        ids.append(u)
+        cts.append(c)
+        ptr.append(ptr[-1] + u.size)
+    rate, done, workers = bench.cpu_baseline_all_cores(
+        np.full(K, 0.1), rng.gamma(100.0, 0.01, (K, V)), np.array(ptr, np.int64),
+        np.concatenate(ids).astype(np.int32), np.concatenate(cts).astype(np.int32), 0.2, 3, docs_per_worker=20)
+    assert workers == 3 and 15 <= done <= 60 and rate > 0
