@@ -77,7 +77,11 @@ def _preload_torch_hip_runtime():
     `import torch` would load the bundled copy as a SECOND runtime and fail with "no
     ROCm-capable device".  Loading torch's copy first (when torch is installed; torch itself is
     not imported) makes both resolve to the same runtime, whatever the import order - which is
-    also what lets the context run on torch's streams for the RCCL all-reduce."""
+    also what lets the context run on torch's streams for the RCCL all-reduce.
+    PYLDA_HIP_RUNTIME=system skips this (a host process that never imports torch; tested in
+    tests/test_gpu_estep.py::test_runs_on_the_system_hip_runtime_without_torch)."""
+    if os.environ.get("PYLDA_HIP_RUNTIME", "") == "system":
+        return
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")

@@ -359,6 +359,20 @@ def test_document_terms_pass_with_underflowing_topics(capi, ap_train, K, alpha0)
     ctx.close()
 
 
+def test_runs_on_the_system_hip_runtime_without_torch():
+    """The library does not need PyTorch: with PYLDA_HIP_RUNTIME=system the loader leaves torch's bundled HIP
+    runtime alone, and a process that never imports torch runs the smoke E-step against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as g; g.smoke(); "
+            "assert 'torch' not in sys.modules, 'torch was imported'; print('no-torch ok')" % root)
+    env = dict(os.environ, PYLDA_HIP_RUNTIME="system")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "no-torch ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_nips_k500_matches_reference_goldens(capi):
     """BASELINE.json cfg 5 in miniature (parsed/nips.88-05, K=500, documents up to 482 distinct terms,
     goldens from the reference itself): exercises the streaming large-K kernel."""
