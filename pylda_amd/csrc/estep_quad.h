@@ -85,9 +85,9 @@ struct QuadLds {
     static constexpr size_t misc = chg + 16;                                       // [8][W]
     static constexpr size_t alf = misc + (size_t)8 * W * 8;                        // [kTopics] alpha (1 beyond K)
     static constexpr size_t gpv = alf + (size_t)kTopics * 8;                       // [kTopics] gamma before the last update
-    static constexpr size_t cnt = gpv + (size_t)kTopics * 8;                       // int32 [2][W * 64] counts of the words a lane finishes
+    static constexpr size_t cnt = gpv + (size_t)kTopics * 8;                       // double [2][W * 64] counts of the words a lane finishes
     static constexpr bool kGlobalCounts = TWL >= 4 || PYLDA_QUAD_FORCE_GCNT;
-    static constexpr size_t rows = (cnt + (kGlobalCounts ? 0 : (size_t)2 * W * 64 * 4) + 255) & ~(size_t)255;   // [16][TWL][kTopics]
+    static constexpr size_t rows = (cnt + (kGlobalCounts ? 0 : (size_t)2 * W * 64 * 8) + 255) & ~(size_t)255;   // [16][TWL][kTopics]
     static constexpr size_t total = rows + (size_t)16 * TWL * kTopics * 8;
     static_assert(TL != 16 || 2 * total <= 160 * 1024, "K <= 128: two workgroups per CU");
     static_assert(total <= 160 * 1024, "fits the LDS");
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     double* misc = reinterpret_cast<double*>(smem + L::misc);
     double* alf = reinterpret_cast<double*>(smem + L::alf);
     double* gpv = reinterpret_cast<double*>(smem + L::gpv);
-    int* cntv = reinterpret_cast<int*>(smem + L::cnt);
+    double* cntv = reinterpret_cast<double*>(smem + L::cnt);    // (as doubles: no int -> fp64 conversion per iteration)
 
 #if PYLDA_QUAD_STAMPS
     long long stamp_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -164,10 +164,12 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     const int word0 = slot0 * 16 + gg, word1 = slot1 * 16 + gg;
     const bool live0 = slot0 < C0 && word0 < N;
     const bool live1 = C1 > 0 && slot1 < WPG && word1 < N;
+    // lanes whose slot exists in this launch class (the transpose rows of the others are never written)
+    const bool exists0 = slot0 < C0, exists1 = C1 > 0 && slot1 < WPG;
     constexpr bool GCNT = L::kGlobalCounts;
     if constexpr (!GCNT) {
-        cntv[tid] = live0 ? p.term_ct[lo + word0] : 0;
-        cntv[NT + tid] = live1 ? p.term_ct[lo + word1] : 0;
+        cntv[tid] = live0 ? (double)p.term_ct[lo + word0] : 0.0;
+        cntv[NT + tid] = live1 ? (double)p.term_ct[lo + word1] : 0.0;
     }
     // kPre: no LDS left for the counts - re-read from global memory every iteration (an L1 / L2 hit requested
     // a whole pass before it is used); the empty asm keeps the compiler from hoisting the load into a VGPR
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             const int ct = p.term_ct[at];
             return (which ? live1 : live0) ? (double)ct : 0.0;
         } else {
-            return (double)cntv[which * NT + tid];
+            return cntv[which * NT + tid];
         }
     };
     double local = 0.0;
@@ -200,8 +202,11 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
                 B[i][2 * jj + 1] = v2.y;
             }
         } else {
+            // a word slot beyond the document: a row of ones, count 0.  Its normaliser is sum_k t_k > 0 (finite
+            // reciprocal), r = 0 * that = 0 and it adds 0 * 1 to every topic sum - without a select per
+            // iteration on r (a zero row would give 0 * (1 / 0))
 #pragma unroll
-            for (int j = 0; j < KRL; ++j) B[i][j] = 0.0;
+            for (int j = 0; j < KRL; ++j) B[i][j] = 1.0;
         }
     }
 #pragma unroll
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             for (int jj = 0; jj < KRL / 2; ++jj) v2[jj] = row[TL * jj];
         } else {
 #pragma unroll
-            for (int jj = 0; jj < KRL / 2; ++jj) v2[jj] = double2{0.0, 0.0};
+            for (int jj = 0; jj < KRL / 2; ++jj) v2[jj] = double2{1.0, 1.0};
         }
 #pragma unroll
         for (int jj = 0; jj < KRL / 2; ++jj) myrows[t * (KT / 2) + TL * jj] = v2[jj];
@@ -353,14 +358,14 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             const double cnt1 = count_of(1);
             // the reciprocal chain of the first chunk runs while the second transpose is in flight; the second
             // chunk's chain is placed behind the first 32 FMAs of pass B (which need r0 only)
-            if (live0 && !(s0 > 1e-280 && s0 < 1e300)) bad = 1;
-            r0 = live0 ? cnt0 * rcp_newton(s0) : 0.0;
+            if (exists0 && !(s0 > 1e-280)) bad = 1;   // (B, t <= 1: a normaliser cannot overflow; NaN fails the compare;
+            r0 = cnt0 * rcp_newton(s0);               //  an empty slot's sum_k t_k is not below any real word's normaliser)
             s1 = finish_sum(h1);
             cnt1h = cnt1;
         } else {
             const double s0 = finish_sum(h0);
-            if (live0 && !(s0 > 1e-280 && s0 < 1e300)) bad = 1;
-            r0 = live0 ? cnt0 * rcp_newton(s0) : 0.0;
+            if (exists0 && !(s0 > 1e-280)) bad = 1;
+            r0 = cnt0 * rcp_newton(s0);
         }
 
         dpp_source_ready(r0);
@@ -390,8 +395,8 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         });
         if constexpr (C1 > 0) {
             asm volatile("" : "+v"(s1));                                  // (keeps the chain below behind the FMAs above)
-            if (live1 && !(s1 > 1e-280 && s1 < 1e300)) bad = 1;
-            r1 = live1 ? cnt1h * rcp_newton(s1) : 0.0;
+            if (exists1 && !(s1 > 1e-280)) bad = 1;
+            r1 = cnt1h * rcp_newton(s1);
             dpp_source_ready(r1);
         }
         row_topic_sums(StaticIndex<0>());
