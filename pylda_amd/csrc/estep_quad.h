@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
                 lds_row_wait(rowbuf);
                 double row[8];
                 rowbuf.unpack(row);
-                pr[t] = dot8(row, tq);
+                pr[t] = TL == 16 ? dot8_two_chains(row, tq) : dot8(row, tq);
                 if constexpr (t + 1 < TWL) request_row(t + 1);
             }
         };
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         if constexpr (C1 > 0) {
             double a1[R1 > 0 ? R1 : 1];
 #pragma unroll
-            for (int i = 0; i < R1; ++i) a1[i] = dot8(B[8 + i], tq);
+            for (int i = 0; i < R1; ++i) a1[i] = TL == 16 ? dot8_two_chains(B[8 + i], tq) : dot8(B[8 + i], tq);
             row_partial(StaticIndex<2>());
             row_partial(StaticIndex<3>());
             if constexpr (TWL > 0) request_row(0);                        // for pass B
