@@ -185,6 +185,11 @@ int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, double* sstats_kern
 int pylda_corpus_plan(pylda_corpus* corpus, int32_t capacity, int32_t* variant, int32_t* geometry,
                       int64_t* documents, int64_t* terms, double* kernel_ms);
 
+/* Layout facts of an uploaded corpus (measurement / test hook): "gather_blocks" - document blocks of the
+ * statistics gather (1: unblocked; set when the first training E-step builds the postings, 0 before),
+ * "gather_segments" - its posting segments.  Returns the value, or a negative pylda_status. */
+int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
+
 /* Tuning / test options:
  *   "doc_values"     1 (default): pylda_get_doc_values returns complete per-document
  *                    log-likelihoods.  0: training fast path - the corpus-level
@@ -197,9 +202,13 @@ int pylda_corpus_plan(pylda_corpus* corpus, int32_t capacity, int32_t* variant, 
  *                    threads, 3 generic global, 4 slab, 6 quilt, 7 streaming, 8 hybrid, 9 wide
  *                    tiered, 10 quad, 11 fused streaming (5 was round 1's column kernel, removed);
  *                    a variant that cannot take a document falls back to the automatic choice;
- *   "quad" (1: documents of <= 208 distinct terms at 64 < K <= 128 run as 4-wavefront workgroups, two
- *   per CU), "quilt_odd", "quilt12", "gather_rows"  A/B switches of kernel geometry
- *                    ("Tried and measured"). */
+ *   "gather_rows"    statistics gather (variational_bayes.py:207): 0 64-topic chunks, 1 whole rows,
+ *                    2 (default) whole rows with the postings fetched in bulk (table stride 128 / 256);
+ *   "gather_blocks"  document blocks of that gather, for corpora created afterwards: -1 (default)
+ *                    automatic - blocks of about one L2 while a (term, block) pair keeps >= 8
+ *                    postings, else unblocked; 0 / 1 off; n > 1 forced (a multiple of 8);
+ *   "quad" (1: documents of <= 224 distinct terms at 64 < K <= 256 run on the quad kernel), "quilt_odd",
+ *   "quilt12", "lds_pad"  A/B switches of kernel geometry ("Tried and measured"). */
 int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value);
 
 /* Test hook: evaluate the device special functions on n host values. */

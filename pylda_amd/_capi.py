@@ -56,6 +56,7 @@ SIGNATURES = {
     "pylda_mstep": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, _c_double_p]),
     "pylda_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pylda_kernel_time": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_int64_p]),
+    "pylda_corpus_layout": (ctypes.c_int64, [_vp, ctypes.c_char_p]),
     "pylda_corpus_plan": (ctypes.c_int, [_vp, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int64_p, _c_int64_p,
                                          _c_double_p]),
     "pylda_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
@@ -405,6 +406,13 @@ class Corpus(object):
         return [{"kernel": self.VARIANT_NAMES.get(int(variant[i]), str(int(variant[i]))), "geometry": int(geometry[i]),
                  "documents": int(documents[i]), "terms": int(terms[i]), "kernel_ms": float(ms[i])}
                 for i in range(n)]
+
+    def layout(self, name):
+        """Layout facts: "gather_blocks", "gather_segments" (include/pylda_hip.h)."""
+        v = self._ctx._lib.pylda_corpus_layout(self._h, name.encode())
+        if v < 0:
+            self._ctx._check(int(v))
+        return int(v)
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):

@@ -109,7 +109,8 @@ struct pylda_ctx {
     int force_logspace = 0;
     int force_variant = -1;
     int quilt12 = 0;
-    int gather_rows = 1;            // whole-row gather kernel for ldk 64 / 128 / 256
+    int gather_rows = 2;            // 0: 64-topic chunks; 1: whole rows (ldk 64 / 128 / 256); 2: + postings in bulk (ldk 128 / 256)
+    int gather_blocks = -1;         // document blocks of the gather: -1 automatic, 0 / 1 off, n forced (multiple of 8)
     int lds_pad = 0;                // A/B: extra dynamic LDS per quad workgroup (forces one workgroup per CU)
     int quad = 1;                   // register + LDS tile kernel (estep_quad.h) for table strides 128 / 256, N <= 208
     int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
@@ -155,6 +156,9 @@ struct pylda_corpus {
     int32_t* d_post_pos = nullptr; // nnz: position in CSR order
     int64_t* d_seg_begin = nullptr;
     int64_t* d_seg_end = nullptr;
+    int32_t* d_exec_order = nullptr;   // document-blocked gather: segment of every (workgroup, wavefront) slot, or -1
+    int64_t exec_slots = 0;
+    int gather_blocks = 1;
     int64_t* d_word_seg_ptr = nullptr;  // V+1
     double* d_partial = nullptr;   // nseg x ldk
     int64_t nseg = 0;
@@ -617,14 +621,79 @@ int build_postings(pylda_corpus* c)
     std::vector<int64_t> seg_begin, seg_end, word_seg_ptr((size_t)V + 1, 0);
     seg_begin.reserve((size_t)(nnz / kSegment + V));
     seg_end.reserve((size_t)(nnz / kSegment + V));
-    for (int v = 0; v < V; ++v) {
-        for (int64_t b = col_ptr[v]; b < col_ptr[v + 1]; b += kSegment) {
-            seg_begin.push_back(b);
-            seg_end.push_back(std::min<int64_t>(b + kSegment, col_ptr[v + 1]));
+    // Document-blocked gather (sstats_kernels.h): NB contiguous document blocks whose t rows fit an XCD's L2,
+    // NB a multiple of the 8 XCDs; only for the whole-row kernel, when all of t exceeds one L2 and a
+    // (term, block) pair still holds >= 8 postings on average.
+    int NB = 1;
+    {
+        const double t_bytes = (double)c->D * ctx->ldk * sizeof(double);
+        const bool rows_kernel = ctx->gather_rows >= 1 && (ctx->ldk == 64 || ctx->ldk == 128 || ctx->ldk == 256);
+        const bool bulk_kernel = ctx->gather_rows == 2 && (ctx->ldk == 128 || ctx->ldk == 256);   // (short segments need it)
+        if (ctx->gather_blocks > 1 && rows_kernel && V > 0) {
+            NB = ctx->gather_blocks;                                  // forced (tests, A/B runs)
+        } else if (ctx->gather_blocks < 0 && bulk_kernel && t_bytes > 8.6e6 && V > 0) {
+            // automatic: blocks of about one L2 (cfg 3 sweep: 16 -> 1.78 ms, 24 -> 1.62, 32 -> ~1.8, 64 -> 3.1; unblocked 3.03)
+            NB = std::max(8, 8 * (int)std::lround(t_bytes / (8 * 4.3e6)));
+            if ((double)nnz / ((double)NB * V) < 8.0) NB = 1;
         }
-        word_seg_ptr[v + 1] = (int64_t)seg_begin.size();
+    }
+    std::vector<int32_t> seg_block;
+    if (NB > 1) {
+        std::vector<int32_t> post_doc((size_t)nnz);
+        if (nnz > 0 && hipMemcpy(post_doc.data(), c->d_post_doc, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(ctx, PYLDA_ERR_HIP, "postings: D2H copy failed");
+        const int64_t per_block = (c->D + NB - 1) / NB;
+        for (int v = 0; v < V; ++v) {
+            int64_t b = col_ptr[v];
+            while (b < col_ptr[v + 1]) {
+                const int32_t blk = (int32_t)(post_doc[(size_t)b] / per_block);
+                int64_t e = b + 1;
+                while (e < col_ptr[v + 1] && e - b < kSegment && post_doc[(size_t)e] / per_block == blk) ++e;
+                seg_begin.push_back(b);
+                seg_end.push_back(e);
+                seg_block.push_back(blk);
+                b = e;
+            }
+            word_seg_ptr[v + 1] = (int64_t)seg_begin.size();
+        }
+    } else {
+        for (int v = 0; v < V; ++v) {
+            for (int64_t b = col_ptr[v]; b < col_ptr[v + 1]; b += kSegment) {
+                seg_begin.push_back(b);
+                seg_end.push_back(std::min<int64_t>(b + kSegment, col_ptr[v + 1]));
+            }
+            word_seg_ptr[v + 1] = (int64_t)seg_begin.size();
+        }
     }
     c->nseg = (int64_t)seg_begin.size();
+    c->gather_blocks = NB;
+    if (NB > 1 && c->nseg > 0) {
+        // XCD x works through the segments of blocks x, x + 8, ... block after block; workgroup g (4 wavefronts)
+        // takes slots 4 * (g / 8) .. + 3 of the list of XCD g % 8
+        constexpr int kXcd = 8;
+        std::vector<std::vector<int32_t>> list(kXcd);
+        {
+            std::vector<std::vector<int32_t>> by_block((size_t)NB);
+            for (int64_t s = 0; s < c->nseg; ++s) by_block[(size_t)seg_block[(size_t)s]].push_back((int32_t)s);
+            for (int b = 0; b < NB; ++b) {
+                auto& dst = list[(size_t)(b % kXcd)];
+                dst.insert(dst.end(), by_block[(size_t)b].begin(), by_block[(size_t)b].end());
+                while (dst.size() % 4) dst.push_back(-1);         // a workgroup never mixes two blocks' rows
+            }
+        }
+        size_t longest = 0;
+        for (const auto& l : list) longest = std::max(longest, l.size());
+        const int64_t groups_per_xcd = (int64_t)(longest / 4);
+        std::vector<int32_t> order((size_t)(groups_per_xcd * kXcd * 4), -1);
+        for (int x = 0; x < kXcd; ++x)
+            for (size_t i = 0; i < list[(size_t)x].size(); ++i)
+                order[(size_t)(((int64_t)(i / 4) * kXcd + x) * 4 + (int64_t)(i % 4))] = list[(size_t)x][i];
+        c->exec_slots = (int64_t)order.size();
+        A(dev_alloc(ctx, &c->d_exec_order, order.size()));
+        if (rc != PYLDA_OK) return rc;
+        if (hipMemcpy(c->d_exec_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(ctx, PYLDA_ERR_HIP, "postings: H2D copy failed");
+    }
     A(dev_alloc(ctx, &c->d_seg_begin, (size_t)c->nseg));
     A(dev_alloc(ctx, &c->d_seg_end, (size_t)c->nseg));
     A(dev_alloc(ctx, &c->d_word_seg_ptr, (size_t)V + 1));
@@ -642,6 +711,9 @@ int build_postings(pylda_corpus* c)
     return PYLDA_OK;
 }
 
+#ifndef PYLDA_GATHER_U
+#define PYLDA_GATHER_U 4        // rows in flight per wavefront (cfg 3, 24 blocks: 4 -> 1.62 ms, 8 -> 1.71, 16 -> 2.3: occupancy)
+#endif
 int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
 {
     const int ldk = ctx->ldk;
@@ -656,16 +728,22 @@ int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
                                c->d_seg_end, c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal,
                                c->d_rfinal, ldk, c->d_partial);
         else if (ctx->gather_rows && (ldk == 64 || ldk == 128 || ldk == 256)) {
-            const dim3 g1((unsigned)((c->nseg + 3) / 4));
-            if (ldk == 64)
+            const dim3 g1((unsigned)(((c->d_exec_order ? c->exec_slots : c->nseg) + 3) / 4));
+            if (ldk == 128 && ctx->gather_rows == 2)
+                hipLaunchKernelGGL((sstats_gather_bulk_kernel<2, PYLDA_GATHER_U>), g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
+                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial, c->d_exec_order);
+            else if (ldk == 256 && ctx->gather_rows == 2)
+                hipLaunchKernelGGL((sstats_gather_bulk_kernel<4, PYLDA_GATHER_U>), g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
+                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial, c->d_exec_order);
+            else if (ldk == 64)
                 hipLaunchKernelGGL(sstats_gather_rows_kernel<1>, g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
-                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial);
+                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial, c->d_exec_order);
             else if (ldk == 128)
                 hipLaunchKernelGGL(sstats_gather_rows_kernel<2>, g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
-                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial);
+                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial, c->d_exec_order);
             else
                 hipLaunchKernelGGL(sstats_gather_rows_kernel<4>, g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
-                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial);
+                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial, c->d_exec_order);
         } else
             hipLaunchKernelGGL(sstats_gather_kernel<64>, grid, dim3(256), 0, ctx->stream, c->d_seg_begin,
                                c->d_seg_end, c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal,
@@ -862,7 +940,10 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "gather_rows")) {
-        ctx->gather_rows = value != 0;
+        ctx->gather_rows = (int)value;               // 0: 64-topic chunks, 1: whole rows, 2: whole rows, postings in bulk
+    } else if (!strcmp(name, "gather_blocks")) {     // (takes effect for corpora created afterwards)
+        if (value > 1 && value % 8) return fail(ctx, PYLDA_ERR_INVALID, "gather_blocks=%lld: a multiple of 8, or -1 / 0 / 1", (long long)value);
+        ctx->gather_blocks = (int)value;
     } else if (!strcmp(name, "quilt_odd")) {
         ctx->quilt_odd = value != 0;
         ctx->plan_epoch += 1;
@@ -990,7 +1071,7 @@ void pylda_corpus_destroy(pylda_corpus* c)
     dev_free(c->d_gamma); dev_free(c->d_doc_ll); dev_free(c->d_doc_wll); dev_free(c->d_iters);
     dev_free(c->d_status); dev_free(c->d_flag_list); dev_free(c->d_flag_count); dev_free(c->d_scalars); dev_free(c->d_entropy_partial);
     dev_free(c->d_tfinal); dev_free(c->d_rfinal); dev_free(c->d_post_doc); dev_free(c->d_post_pos);
-    dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial);
+    dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial); dev_free(c->d_exec_order);
     delete c;
 }
 
@@ -1462,6 +1543,14 @@ int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, double* sstats_kern
     ctx->doc_kernel_ms = ctx->sstats_kernel_ms = 0.0;
     ctx->estep_calls = 0;
     return PYLDA_OK;
+}
+
+int64_t pylda_corpus_layout(pylda_corpus* c, const char* name)
+{
+    if (!c || !name) return PYLDA_ERR_INVALID;
+    if (!strcmp(name, "gather_blocks")) return c->have_postings ? c->gather_blocks : 0;
+    if (!strcmp(name, "gather_segments")) return c->have_postings ? c->nseg : 0;
+    return fail(c->ctx, PYLDA_ERR_INVALID, "corpus_layout: unknown name '%s'", name);
 }
 
 int pylda_corpus_plan(pylda_corpus* c, int32_t capacity, int32_t* variant, int32_t* geometry, int64_t* documents,

@@ -62,16 +62,26 @@ __global__ __launch_bounds__(256) void sstats_gather_kernel(
 // Whole-row variant for ldk = 64*NCH (NCH = 1, 2, 4): one wavefront accumulates all topics of a
 // segment, so each posting's t_d row is one contiguous ldk*8-byte read and the posting index is
 // loaded once instead of once per 64-topic chunk.
+//
+// Document-blocked mode (exec_order != nullptr; capi.hip build_postings).  A term's postings are in document
+// order, so cutting its segments at the boundaries of NB contiguous document blocks costs nothing - and a block's
+// t rows (<= 3.3 MB) fit one XCD's 4 MB L2.  Workgroups are dispatched round-robin over the 8 XCDs, so workgroup g
+// takes its four segments from the list of XCD g % 8, which holds the segments of blocks g % 8, g % 8 + 8, ...
+// block after block: the t rows a CU gathers are then hits in ITS L2 instead of reads over the fabric (the
+// unblocked gather runs at the fabric's ~6.7 TB/s for L2 misses, wherever the rows live).  The price is one
+// partial row per (term, block): worth it while a pair holds >= 8 postings (cfg 3: 12; cfg 4: 3 - unblocked).
 template <int NCH>
 __global__ __launch_bounds__(256) void sstats_gather_rows_kernel(
     const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end, int64_t nseg,
     const int32_t* __restrict__ post_doc, const int32_t* __restrict__ post_pos,
-    const double* __restrict__ tfinal, const double* __restrict__ rfinal, double* __restrict__ partial)
+    const double* __restrict__ tfinal, const double* __restrict__ rfinal, double* __restrict__ partial,
+    const int32_t* __restrict__ exec_order)
 {
     constexpr int ldk = 64 * NCH;
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t seg = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave;
-    if (seg >= nseg) return;
+    int64_t seg = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave;
+    if (exec_order) seg = exec_order[seg];          // (the grid covers the padded list exactly; -1: no segment)
+    if (seg < 0 || seg >= nseg) return;
     const int64_t b = seg_begin[seg], e = seg_end[seg];
     double acc0[NCH], acc1[NCH];
 #pragma unroll
@@ -95,6 +105,65 @@ __global__ __launch_bounds__(256) void sstats_gather_rows_kernel(
     }
 #pragma unroll
     for (int j = 0; j < NCH; ++j) partial[(size_t)seg * ldk + lane + 64 * j] = acc0[j] + acc1[j];
+}
+
+// The same pass with the postings' metadata fetched in bulk.  The kernel above walks a segment two postings at a
+// time, each step a chain of three dependent fetches (posting -> r_dn at a random CSR position -> the t row):
+// with 32 wavefronts per CU and two 1-KiB rows in flight each that is ~6.7 TB/s at ~2.5 us per step - the
+// "ceiling" rounds 1 and 2 measured was this chain, not the fabric.  Here a wavefront loads up to 64 postings of
+// its segment at once (lane l: document, position, then r), then walks them with the document and r of posting p
+// read from lane p (v_readlane: scalar row base + lane offset, scalar multiplier), U rows in flight per wavefront,
+// 16 bytes per lane and load.  Topic of (lane, piece j, half c): 128 j + 2 lane + c.  Fixed summation order.
+template <int NCH, int U>
+__global__ __launch_bounds__(256) void sstats_gather_bulk_kernel(
+    const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end, int64_t nseg,
+    const int32_t* __restrict__ post_doc, const int32_t* __restrict__ post_pos,
+    const double* __restrict__ tfinal, const double* __restrict__ rfinal, double* __restrict__ partial,
+    const int32_t* __restrict__ exec_order)
+{
+    static_assert(NCH == 2 || NCH == 4, "table stride 128 or 256");
+    static_assert(64 % U == 0, "whole trips over a 64-posting chunk");
+    constexpr int ldk = 64 * NCH, NP = NCH / 2;
+    const int lane = threadIdx.x & (kWave - 1);
+    int64_t seg = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave;
+    if (exec_order) seg = exec_order[seg];
+    if (seg < 0 || seg >= nseg) return;
+    const int64_t b = seg_begin[seg], e = seg_end[seg];
+    f64x2 acc[U][NP];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc[u][j] = f64x2{0.0, 0.0};
+    for (int64_t chunk = b; chunk < e; chunk += kWave) {
+        const int n = (int)(e - chunk < kWave ? e - chunk : kWave);
+        const bool mine = lane < n;
+        const int d = mine ? post_doc[chunk + lane] : 0;                  // lanes beyond the segment: row 0 times r = 0
+        const double r = mine ? rfinal[post_pos[chunk + lane]] : 0.0;
+        for (int p = 0; p < n; p += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int doc = __builtin_amdgcn_readlane(d, p + u);
+                const double rr = readlane_f64(r, p + u);
+                const f64x2* row = reinterpret_cast<const f64x2*>(tfinal + (size_t)doc * ldk) + lane;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const f64x2 t2 = row[64 * j];
+                    acc[u][j].x = fma(rr, t2.x, acc[u][j].x);
+                    acc[u][j].y = fma(rr, t2.y, acc[u][j].y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        f64x2 s = acc[0][j];
+#pragma unroll
+        for (int u = 1; u < U; ++u) {
+            s.x += acc[u][j].x;
+            s.y += acc[u][j].y;
+        }
+        reinterpret_cast<f64x2*>(partial + (size_t)seg * ldk)[lane + 64 * j] = s;
+    }
 }
 
 // sstats[w][k] = B[w][k] * sum over the word's segments (in order).

@@ -359,6 +359,40 @@ def test_document_terms_pass_with_underflowing_topics(capi, ap_train, K, alpha0)
     ctx.close()
 
 
+@pytest.mark.parametrize("K,blocks,rows", [(128, 8, 2), (128, 16, 2), (256, 8, 2), (100, 24, 1), (128, 0, 1), (64, 8, 2)])
+def test_document_blocked_statistics_gather(capi, ap_train, K, blocks, rows):
+    """variational_bayes.py:207 as a gather over the postings: cutting a term's segments at document-block
+    boundaries and running them in XCD order (option gather_blocks, automatic only for corpora whose t rows
+    exceed the L2) must give the same statistics as the unblocked pass - same terms, another summation order -
+    and the oracle's."""
+    from oracle import c_oracle
+    g = ap_train
+    rng = np.random.default_rng(K + blocks)
+    ptr = g["doc_ptr"][:401]
+    tid, tct = g["term_id"][:ptr[-1]], g["term_ct"][:ptr[-1]]
+    eta = rng.gamma(100.0, 0.01, (K, 6806))
+    alpha = rng.uniform(0.05, 1.0, K)
+    out = {}
+    for nb in (0, blocks):
+        ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_rows", rows)
+        ctx.set_option("gather_blocks", nb)
+        corpus = ctx.corpus(ptr, tid, tct)
+        res = ctx.estep_host(corpus, alpha, eta)
+        out[nb] = (res["sstats"], res["document_log_likelihood"])
+        assert corpus.layout("gather_blocks") == max(1, nb)
+        ctx.set_option("doc_values", 0)                  # the corpus entropy term comes from the same pass
+        ctx.estep(corpus)
+        assert abs(ctx.estep_results(corpus)[0] - res["document_log_likelihood"]) < 1e-11 * abs(res["document_log_likelihood"])
+        corpus.close()
+        ctx.close()
+    ref = c_oracle.e_step(alpha, eta, ptr, tid, tct)
+    assert np.max(np.abs(out[blocks][0] - out[0][0])) < 1e-11
+    assert np.max(np.abs(out[blocks][0] - ref["sstats"])) < SSTATS_ATOL
+    assert abs(out[blocks][0].sum() - tct.sum()) < 1e-7
+    assert out[blocks][1] == out[0][1]
+
+
 def test_runs_on_the_system_hip_runtime_without_torch():
     """The library does not need PyTorch: with PYLDA_HIP_RUNTIME=system the loader leaves torch's bundled HIP
     runtime alone, and a process that never imports torch runs the smoke E-step against the oracle."""
