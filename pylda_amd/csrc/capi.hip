@@ -632,9 +632,19 @@ int build_postings(pylda_corpus* c)
         if (ctx->gather_blocks > 1 && rows_kernel && V > 0) {
             NB = ctx->gather_blocks;                                  // forced (tests, A/B runs)
         } else if (ctx->gather_blocks < 0 && bulk_kernel && t_bytes > 8.6e6 && V > 0) {
-            // automatic: blocks of about one L2 (cfg 3 sweep: 16 -> 1.78 ms, 24 -> 1.62, 32 -> ~1.8, 64 -> 3.1; unblocked 3.03)
-            NB = std::max(8, 8 * (int)std::lround(t_bytes / (8 * 4.3e6)));
-            if ((double)nnz / ((double)NB * V) < 8.0) NB = 1;
+            // automatic: blocks of about one L2 (cfg 3 sweep: 16 -> 1.78 ms, 24 -> 1.62, 32 -> ~1.8, 64 -> 3.1; unblocked 3.03),
+            // but no more than leave a (term, block) pair 8 postings on average - every pair costs a partial row
+            // (cfg 4, t = 2 GB: 64 blocks 55 ms, 128 53, 256 48, unblocked 65; 240 by this rule) - and no more
+            // partial rows than fit a quarter of the free device memory
+            const int by_l2 = std::max(8, 8 * (int)std::lround(t_bytes / (8 * 4.3e6)));
+            const int by_pairs = (int)std::min<double>(1e6, (double)nnz / (8.0 * V)) / 8 * 8;
+            NB = std::min(by_l2, by_pairs);
+            size_t free_b = 0, total_b = 0;
+            if (NB >= 8 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const double row = (double)ctx->ldk * sizeof(double);
+                while (NB >= 8 && ((double)V * NB + (double)nnz / kSegment) * row > 0.25 * (double)free_b) NB -= 8;
+            }
+            if (NB < 8) NB = 1;
         }
     }
     std::vector<int32_t> seg_block;
@@ -647,8 +657,10 @@ int build_postings(pylda_corpus* c)
             int64_t b = col_ptr[v];
             while (b < col_ptr[v + 1]) {
                 const int32_t blk = (int32_t)(post_doc[(size_t)b] / per_block);
+                const int64_t block_end = ((int64_t)blk + 1) * per_block;       // first document of the next block
+                const int64_t cap = std::min<int64_t>(col_ptr[v + 1], b + kSegment);
                 int64_t e = b + 1;
-                while (e < col_ptr[v + 1] && e - b < kSegment && post_doc[(size_t)e] / per_block == blk) ++e;
+                while (e < cap && post_doc[(size_t)e] < block_end) ++e;
                 seg_begin.push_back(b);
                 seg_end.push_back(e);
                 seg_block.push_back(blk);
