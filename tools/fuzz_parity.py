@@ -8,7 +8,7 @@ from oracle import c_oracle
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0 = time.time()
-cases = worst_ll = worst_g = worst_fast = 0
+cases = worst_ll = worst_g = worst_fast = worst_ss = 0
 flips = docs = 0
 while time.time() - t0 < budget:
     K = int(rng.choice([1, 2, 7, 10, 16, 31, 33, 64, 65, 100, 127, 128, 129, 160, 192, 200, 255, 256, 257, 300, 384, 400, 500, 512]))
@@ -28,6 +28,8 @@ while time.time() - t0 < budget:
     tol = float(rng.choice([1e-6, 1e-6, 1e-4, 1e-8]))
     ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, 50, tol)
     ctx = _capi.Context(K, V)
+    ctx.set_option("gather_blocks", int(rng.choice([-1, 0, 8, 16, 40])))      # statistics gather: automatic / unblocked / forced blocks
+    ctx.set_option("gather_rows", int(rng.choice([0, 1, 2, 2])))
     corpus = ctx.corpus(ptr, ids, cts)
     out = ctx.estep_host(corpus, alpha, eta, 50, tol, False)
     ctx.set_option("doc_values", 0)
@@ -40,6 +42,9 @@ while time.time() - t0 < budget:
         worst_g = max(worst_g, float(np.max(np.abs(out["gamma"][same] - ref["gamma"][same]) / ref["gamma"][same])))
     if (~same).any():
         assert np.max(np.abs(out["doc_ll"][~same] - ref["doc_ll"][~same]) / np.maximum(1.0, np.abs(ref["doc_ll"][~same]))) < 1e-5
+    if same.all():          # (a document that stops one iteration apart carries a different phi into the statistics)
+        worst_ss = max(worst_ss, float(np.max(np.abs(out["sstats"] - ref["sstats"]))))
+        assert worst_ss < 1e-8, (K, V, D, mean_len, worst_ss)
     full = out["document_log_likelihood"]
     worst_fast = max(worst_fast, abs(fast - full) / max(1.0, abs(full)))
     assert worst_ll < 1e-9 and worst_g < 1e-6 and worst_fast < 1e-10, (K, V, D, mean_len, worst_ll, worst_g, worst_fast, [c["kernel"] for c in corpus.plan()])
@@ -52,5 +57,5 @@ while time.time() - t0 < budget:
                      out["gamma"][d, k], ref["gamma"][d, k], alpha[k]))
     corpus.close(); ctx.close()
     cases += 1
-print("fuzz: %d cases, %d documents, %d iteration-count flips; worst rel doc-LL %.2e, gamma %.2e, fast-path corpus LL %.2e"
-      % (cases, docs, flips, worst_ll, worst_g, worst_fast))
+print("fuzz: %d cases, %d documents, %d iteration-count flips; worst rel doc-LL %.2e, gamma %.2e, fast-path corpus LL %.2e, statistics abs %.2e"
+      % (cases, docs, flips, worst_ll, worst_g, worst_fast, worst_ss))
