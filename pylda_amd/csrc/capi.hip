@@ -1451,7 +1451,7 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* t
                        ctx->d_sstats, ctx->d_beta, K, V, ctx->ldk, ctx->d_eta);                                               // :226
     int nblocks = 0;
     if (alpha_ss_k) {
-        nblocks = (int)std::min<int64_t>(512, std::max<int64_t>(1, (c->D + 3) / 4));
+        nblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (c->D + 3) / 4));     // (ctx->d_partial holds 1024 rows)
         hipLaunchKernelGGL(mstep_alpha_ss_kernel, dim3(nblocks), dim3(256), (size_t)4 * K * sizeof(double),
                            ctx->stream, c->d_gamma, c->D, K, ctx->d_partial);                                       // :232
         hipLaunchKernelGGL(column_sum_kernel, dim3((K + 63) / 64), dim3(256), 0, ctx->stream, ctx->d_partial,

@@ -78,13 +78,27 @@ __global__ __launch_bounds__(256) void mstep_alpha_ss_kernel(const double* __res
     double* acc = reinterpret_cast<double*>(smem);        // 4 x K
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     for (int k = lane; k < K; k += kWave) acc[wave * K + k] = 0.0;
-    for (int64_t d = (int64_t)blockIdx.x * 4 + wave; d < D; d += (int64_t)gridDim.x * 4) {
-        const double* g = gamma + (size_t)d * K;
-        double s = 0.0;
-        for (int k = lane; k < K; k += kWave) s += g[k];
-        s = wave_sum(s);
-        const double ps = digamma(s);
-        for (int k = lane; k < K; k += kWave) acc[wave * K + k] += digamma(g[k]) - ps;
+    // two documents per trip: the second one's gamma row is in flight while the first one's digammas run
+    // (per document a chain of row fetch -> wavefront sum -> digamma; with 1024 workgroups = 4 wavefronts per
+    // SIMD the whole device M-step went from 3.4 to 2.7 ms at cfg 4 - the rest is the 2.6e8 digammas themselves)
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t d = (int64_t)blockIdx.x * 4 + wave; d < D; d += 2 * stride) {
+        const double* g0 = gamma + (size_t)d * K;
+        const bool two = d + stride < D;
+        const double* g1 = two ? gamma + (size_t)(d + stride) * K : g0;
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = lane; k < K; k += kWave) {
+            s0 += g0[k];
+            s1 += g1[k];
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        const double ps0 = digamma(s0), ps1 = digamma(s1);
+        for (int k = lane; k < K; k += kWave) {
+            double a = acc[wave * K + k] + (digamma(g0[k]) - ps0);
+            if (two) a += digamma(g1[k]) - ps1;
+            acc[wave * K + k] = a;
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += 256)
