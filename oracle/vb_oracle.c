@@ -15,7 +15,7 @@
  *
  * Parity pinning: tests/test_oracle_golden.py checks this file against the
  * golden vectors produced by running the reference itself in the build
- * container (tests/golden/*.npz) and against scipy samples
+ * container (the npz fixtures under tests/golden) and against scipy samples
  * (tests/golden/special_fn.npz).
  *
  * Build: gcc -O2 -fPIC -shared -o liboracle_vb.so vb_oracle.c -lm
