@@ -289,7 +289,9 @@ def measure(job, args, name, steps, warmup, docs=None):
                      "kernel": "E-step document kernels (concurrent launch classes) + sufficient-statistics pass "
                                "(gather + finalize), rank 0, HIP events on the launch streams",
                      "kernel_ms": kernel_ms, "kernel_ms_documents": doc_ms, "kernel_ms_sstats": ss_ms,
-                     "algorithmic_bytes": B, "launch_classes": classes},
+                     "algorithmic_bytes": B, "launch_classes": classes,
+                     "statistics_gather": {"document_blocks": vb._train_corpus.layout("gather_blocks"),
+                                           "segments": vb._train_corpus.layout("gather_segments")}},
         "joint_log_likelihood": joint,
         "startup": {"generate_corpus_s": t_gen, "upload_and_schedule_s": t_init,
                     "first_%d_steps_s" % first_steps: t_first,
