@@ -25,9 +25,15 @@ Workloads (BASELINE.json configs):
 
 The default run prints ONE JSON line on rank 0: the primary record (cfg 3) with
 `roofline` and `cpu_baseline`, and as sub-records the other configurations timed
-the same way in the same process: `synth1m` (cfg 4, every N), and at N = 1 also
-`ap_k10` (cfg 2) and `nips_k500` (cfg 5, with the held-out per-token
-log-likelihood after 50 iterations against the reference's own value).
+in the same processes at every N: `synth1m` (cfg 4), `ap_k10` (cfg 2) and
+`nips_k500` (cfg 5: the 50-iteration joint log-likelihood trace asserted against
+the reference's own, held-out per-token log-likelihood after 50 iterations).
+
+Protocol: 3 warm-up outer iterations from the seeded start, then
+outer iterations 4-8 are THE timed window, whatever --steps / --warmup say: timed
+step i is iteration 4 + (i mod 5); after iteration 8 the model returns to its
+state after iteration 3 (a device checkpoint restored inside the timed region).
+`--steps 5 --warmup 3` and `--steps 20 --warmup 5` therefore time the same work.
 
 roofline: HBM bound, algorithmic bytes B = nnz*(8+16K) + D*(8K+8) per E-step
  over the kernels that move them - the document kernels of the E-step
@@ -50,6 +56,8 @@ import numpy as np
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec)
 CHUNK = 25000
+PROTOCOL_WARMUP = 3             # three warm-up outer iterations ...
+PROTOCOL_WINDOW = 5             # ... then outer iterations 4-8 are the timed window
 
 # (documents, nnz, sum of term ids, sum of counts) of the generated corpora: numpy PCG64 draws
 # (pylda_amd/corpus.py::synthetic_lda_shard), independent of torch version and device.
@@ -61,6 +69,40 @@ EXPECTED_CHECKSUM = {
 
 def algorithmic_bytes(nnz, D, K):
     return nnz * (8 + 16 * K) + D * (8 * K + 8)
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources whose HBM traffic profiles/traffic_*.json describes."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "pylda_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.startswith("estep_") or f in ("sstats_kernels.h", "doc_terms.h"):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_record(name):
+    """roofline.traffic: HBM bytes per E-step from the committed rocprofv3 --pmc passes of this workload
+    (tools/profile_bench.sh writes profiles/traffic_<workload>.json with the hash of the kernel sources it
+    profiled).  A file made with other kernel sources is reported as stale, not as a measurement."""
+    if name is None:
+        return None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % name)
+    if not os.path.exists(tpath):
+        return None, None
+    try:
+        rec = json.load(open(tpath))
+    except Exception:
+        return None, None
+    have, want = rec.get("kernel_source_hash"), kernel_source_hash()
+    if have != want:
+        return None, "profiles/traffic_%s.json is STALE (kernel sources %s, profiled %s): %s bytes per E-step then" \
+            % (name, want, have, rec.get("hbm_bytes_per_launch"))
+    return rec.get("hbm_bytes_per_launch"), \
+        "profiles/traffic_%s.json (rocprofv3 --pmc passes of this workload and these kernel sources [%s], corrected " \
+        "per MI355X_MICROARCH.md; not re-measured in this run)" % (name, want)
 
 
 def build_workload(name, rank, world, device, docs_override=None):
@@ -237,29 +279,59 @@ def measure(job, args, name, steps, warmup, docs=None):
     if job.group is None:
         distributed.bind_to_torch_stream(ctx)
 
+    # ---- SURVEY 8d protocol: 3 warm-up outer iterations from the seeded start, then outer iterations 4-8 timed.
+    # The window is the same whatever --steps / --warmup say: a timed step is iteration 4 + (i mod 5), and after
+    # iteration 8 the model goes back to its state after iteration 3 (device checkpoint of eta, pylda_model_checkpoint;
+    # alpha and the counter on the host) INSIDE the timed region - every step runs the whole E-step, exchange and
+    # M-step, nothing is cached.  --warmup beyond 3 runs further window steps untimed.
     t_first = time.perf_counter()
-    first_steps = max(1, warmup)
-    for _ in range(first_steps):
+    for _ in range(PROTOCOL_WARMUP):
         vb.learning()
     job.torch.cuda.synchronize()
     t_first = time.perf_counter() - t_first      # includes the one-off postings (CSC) build of the first E-step
+    ctx.model_checkpoint()
+    alpha_ckpt, counter_ckpt = vb._alpha_alpha.copy(), vb._counter
+
+    state = {"pos": 0}
+
+    def window_step():
+        if state["pos"] == PROTOCOL_WINDOW:
+            ctx.model_checkpoint(restore=True)
+            vb._alpha_alpha = alpha_ckpt.copy()
+            vb._counter = counter_ckpt
+            state["pos"] = 0
+        state["pos"] += 1
+        return vb.learning()
+
+    for _ in range(max(0, warmup - PROTOCOL_WARMUP)):
+        window_step()
+    job.torch.cuda.synchronize()
     ctx.set_profiling(True)
     ctx.kernel_time()
+    ctx.work_counters()
     vb._train_corpus.plan()
     job.barrier()
-    t0 = time.perf_counter()
+    stamps = [time.perf_counter()]
+    positions = []
     for _ in range(steps):
-        joint = vb.learning()
+        joint = window_step()
+        positions.append(state["pos"])
+        stamps.append(time.perf_counter())
     job.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - stamps[0]
     doc_ms, ss_ms, calls = ctx.kernel_time()
+    sum_iters, sum_iter_terms = ctx.work_counters()
     classes = vb._train_corpus.plan()
     ctx.set_profiling(False)
+    step_ms = np.diff(np.array(stamps)) * 1e3
+    per_position = [float(np.mean([m for m, q in zip(step_ms, positions) if q == pos + 1] or [np.nan]))
+                    for pos in range(PROTOCOL_WINDOW)]
 
     elapsed = job.reduce([elapsed], "max")[0]
-    sums = job.reduce([float(D_local), float(nnz_local)] + [float(x) for x in corpus_checksum(ptr, ids, cts)])
+    sums = job.reduce([float(D_local), float(nnz_local), sum_iters] + [float(x) for x in corpus_checksum(ptr, ids, cts)])
     nnz_max = job.reduce([float(nnz_local)], "max")[0]
-    D_total, nnz_total = int(sums[0]), int(sums[1])
+    D_total, nnz_total, sum_iters_total = int(sums[0]), int(sums[1]), sums[2]
+    sums = sums[:2] + sums[3:]
     calls = max(1, calls)
     doc_ms, ss_ms = doc_ms / calls, ss_ms / calls
     for c in classes:
@@ -267,17 +339,20 @@ def measure(job, args, name, steps, warmup, docs=None):
     B = algorithmic_bytes(nnz_local, D_local, K)
     kernel_ms = doc_ms + ss_ms
     achieved = B / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % name)
-    if os.path.exists(tpath) and docs is None:
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            traffic_source = "profiles/traffic_%s.json (rocprofv3 --pmc passes of this workload, corrected per " \
-                             "MI355X_MICROARCH.md; not re-measured in this run)" % name
-        except Exception:
-            traffic = None
+    traffic, traffic_source = traffic_record(name if docs is None else None)
+    flops = 4.0 * K * sum_iter_terms / calls          # two mat-vecs per inner iteration actually executed, rank 0
+    tflops = flops / (doc_ms * 1e-3) / 1e12 if doc_ms > 0 else 0.0
     rec = {
         "value": D_total * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "scaling": wl["scaling"],
+        "doc_iterations_per_s": sum_iters_total / elapsed,
+        "protocol": {"warmup_outer_iterations": PROTOCOL_WARMUP,
+                     "window": "outer iterations %d-%d from the seeded start (SURVEY 8d); step i of the timed region is "
+                               "iteration %d + (i mod %d), the model returns to its state after iteration %d through a "
+                               "device checkpoint inside the timed region" % (PROTOCOL_WARMUP + 1, PROTOCOL_WARMUP + PROTOCOL_WINDOW,
+                                                                             PROTOCOL_WARMUP + 1, PROTOCOL_WINDOW, PROTOCOL_WARMUP),
+                     "median_ms_per_step": float(np.median(step_ms)),
+                     "ms_per_window_iteration": per_position,
+                     "mean_inner_iterations": sum_iters / calls / max(1, D_local)},
         "config": {"workload": wl["label"], "docs_total": D_total, "nnz_total": nnz_total,
                    "docs_per_gpu": D_local, "nnz_per_gpu": nnz_local, "tokens_per_gpu": tokens_local,
                    "nnz_imbalance": nnz_max * job.world / max(1, nnz_total) - 1.0,
@@ -292,9 +367,14 @@ def measure(job, args, name, steps, warmup, docs=None):
                      "algorithmic_bytes": B, "launch_classes": classes,
                      "statistics_gather": {"document_blocks": vb._train_corpus.layout("gather_blocks"),
                                            "segments": vb._train_corpus.layout("gather_segments")}},
+        # the honest companion: the document kernels are fp64-VALU / latency bound, not HBM bound;
+        # flops = 4 K sum_d I_d N_d of the inner iterations executed IN THE TIMED WINDOW (device counters)
+        "roofline_fp64": {"bound": "fp64 vector FMA", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": flops,
+                          "mean_inner_iterations": sum_iters / calls / max(1, D_local)},
         "joint_log_likelihood": joint,
         "startup": {"generate_corpus_s": t_gen, "upload_and_schedule_s": t_init,
-                    "first_%d_steps_s" % first_steps: t_first,
+                    "first_%d_steps_s" % PROTOCOL_WARMUP: t_first,
                     "note": "the first E-step also builds the corpus' postings (CSC) for the statistics gather"},
     }
     expected = EXPECTED_CHECKSUM.get(name)
@@ -302,17 +382,6 @@ def measure(job, args, name, steps, warmup, docs=None):
         assert rec["config"]["corpus_checksum"] == expected, \
             "generated corpus differs from the recorded one: %r vs %r" % (rec["config"]["corpus_checksum"], expected)
     return rec, vb, ctx, wl
-
-
-def fp64_companion(ctx, vb, ptr, K, kernel_ms_documents):
-    """The honest companion: the document kernels are fp64-VALU / latency bound, not HBM bound.
-    flops of the inner loops actually executed = sum_d I_d * 4 * N_d * K (two mat-vecs per iteration)."""
-    _, _, iters = ctx.get_doc_values(vb._train_corpus, want_ll=False)
-    work = float(np.dot(iters.astype(np.float64), np.diff(ptr).astype(np.float64))) * 4.0 * K
-    tflops = work / (kernel_ms_documents * 1e-3) / 1e12 if kernel_ms_documents > 0 else 0.0
-    return {"bound": "fp64 vector FMA", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
-            "flops_per_launch": work, "mean_inner_iterations": float(iters.mean())}
 
 
 def cpu_leg(ctx, vb, wl, args, budget_s, max_docs, value, all_cores=0):
@@ -400,12 +469,10 @@ def main():
             "scaling": rec["scaling"], "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if args.workload.startswith("synth") else "parsed corpus fixture (tests/golden)",
             "config": rec["config"], "roofline": rec["roofline"],
+            "roofline_fp64": rec["roofline_fp64"], "doc_iterations_per_s": rec["doc_iterations_per_s"],
+            "protocol": rec["protocol"],
             "joint_log_likelihood": rec["joint_log_likelihood"], "startup": rec["startup"],
         }
-        try:
-            out["roofline_fp64"] = fp64_companion(ctx, vb, wl["ptr"], K, rec["roofline"]["kernel_ms_documents"])
-        except Exception as exc:
-            out["roofline_fp64"] = {"error": str(exc)}
         if not args.no_cpu_baseline and job.world == 1:
             out.update(cpu_leg(ctx, vb, wl, args, args.cpu_seconds, 2000, rec["value"], all_cores=args.cpu_workers))
     release(vb)
@@ -415,16 +482,13 @@ def main():
     if extras:
         # ---- cfg 4 (1M documents, K=256) alongside, every N: strong scaling + its own roofline ----
         try:
-            rec4, vb4, ctx4, wl4 = measure(job, args, "synth1m", 3, 2, args.extra_docs)
+            rec4, vb4, ctx4, wl4 = measure(job, args, "synth1m", PROTOCOL_WINDOW, PROTOCOL_WARMUP, args.extra_docs)
             if job.rank == 0:
-                sub = {"value": rec4["value"], "unit": "docs/s", "n_gpus": job.world, "steps": 3, "warmup": 2,
-                       "ms_per_step": rec4["ms_per_step"], "scaling": "strong", "config": rec4["config"],
-                       "roofline": rec4["roofline"], "startup": rec4["startup"]}
-                try:
-                    sub["roofline_fp64"] = fp64_companion(ctx4, vb4, wl4["ptr"], wl4["K"],
-                                                          rec4["roofline"]["kernel_ms_documents"])
-                except Exception as exc:
-                    sub["roofline_fp64"] = {"error": str(exc)}
+                sub = {"value": rec4["value"], "unit": "docs/s", "n_gpus": job.world, "steps": PROTOCOL_WINDOW,
+                       "warmup": PROTOCOL_WARMUP, "ms_per_step": rec4["ms_per_step"], "scaling": "strong",
+                       "config": rec4["config"], "roofline": rec4["roofline"], "roofline_fp64": rec4["roofline_fp64"],
+                       "doc_iterations_per_s": rec4["doc_iterations_per_s"], "protocol": rec4["protocol"],
+                       "startup": rec4["startup"]}
                 if not args.no_cpu_baseline and job.world == 1:
                     sub.update(cpu_leg(ctx4, vb4, wl4, args, min(args.cpu_seconds, 10.0), 400, rec4["value"]))
                 out["synth1m"] = sub
@@ -436,14 +500,20 @@ def main():
             if job.group is not None:
                 raise
             out["synth1m"] = {"error": repr(exc)}
+    if extras:
+        # ---- cfg 2 (associated-press K=10) and cfg 5 (nips.88-05 K=500), every N: documents sharded over the ranks ----
+        for key, fn in (("ap_k10", ap_extra), ("nips_k500", nips_extra)):
+            try:
+                sub = fn(job, args)
+                if job.rank == 0:
+                    out[key] = sub
+            except AssertionError:
+                raise
+            except Exception as exc:                # the fixture may be absent in a stripped tree
+                if job.group is not None:
+                    raise
+                out[key] = {"error": repr(exc)}
     if job.rank == 0:
-        if extras and job.world == 1:
-            from pylda_amd import _capi
-            for key, fn in (("ap_k10", ap_extra), ("nips_k500", nips_extra)):
-                try:
-                    out[key] = fn(_capi, args)
-                except Exception as exc:            # the fixture may be absent in a stripped tree
-                    out[key] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     if job.group is not None:
         import torch.distributed as dist
@@ -462,13 +532,21 @@ def launcher_argv(gpus, argv):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def ap_extra(_capi, args):
-    """BASELINE.json cfg 2: AP K=10 E-step on one GPU vs the CPU path and the goldens."""
+def ap_extra(job, args):
+    """BASELINE.json cfg 2: AP K=10 E-step vs the CPU path and the goldens; at N > 1 the 2000 documents are
+    sharded (nnz-balanced contiguous ranges), every rank runs the E-step on its shard."""
+    from pylda_amd import _capi
+    from pylda_amd.corpus import shard_bounds
     g = np.load(os.path.join(ROOT, "tests", "golden", "ap_train_k10.npz"))
     ptr, ids, cts = g["doc_ptr"].astype(np.int64), g["term_id"].astype(np.int32), g["term_ct"].astype(np.int32)
     alpha, eta = g["alpha"], g["eta"]
-    ctx = _capi.Context(10, eta.shape[1])
-    corpus = ctx.corpus(ptr, ids, cts)
+    D_total = len(ptr) - 1
+    bounds = shard_bounds(ptr, job.world)
+    lo, hi = int(bounds[job.rank]), int(bounds[job.rank + 1])
+    sptr = ptr[lo:hi + 1] - ptr[lo]
+    sids, scts = ids[ptr[lo]:ptr[hi]], cts[ptr[lo]:ptr[hi]]
+    ctx = _capi.Context(10, eta.shape[1], device=job.local_rank)
+    corpus = ctx.corpus(sptr, sids, scts)
     ctx.set_alpha(alpha)
     ctx.set_eta(eta)
     for _ in range(3):
@@ -477,20 +555,24 @@ def ap_extra(_capi, args):
     reps = 20
     ctx.set_profiling(True)
     ctx.kernel_time()
+    job.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
         ctx.estep(corpus)
         ctx.estep_results(corpus)
-    gpu_rate = 2000 * reps / (time.perf_counter() - t0)
+    job.barrier()
+    elapsed = job.reduce([time.perf_counter() - t0], "max")[0]
+    gpu_rate = D_total * reps / elapsed
     doc_ms, ss_ms, calls = ctx.kernel_time()
     ctx.set_profiling(False)
     doc_ll, _, iters = ctx.get_doc_values(corpus)
-    delta = np.abs(doc_ll - g["doc_ll"]) / np.abs(g["doc_ll"])
-    out = {"gpu_docs_per_s": gpu_rate, "estep_ms": 2000.0 / gpu_rate * 1e3,
+    delta = np.abs(doc_ll - g["doc_ll"][lo:hi]) / np.abs(g["doc_ll"][lo:hi])
+    worst, same = job.reduce([float(delta.max())], "max")[0], job.reduce([float(np.sum(iters == g["iters"][lo:hi]))])[0]
+    out = {"gpu_docs_per_s": gpu_rate, "n_gpus": job.world, "estep_ms": elapsed / reps * 1e3,
            "kernel_ms_documents": doc_ms / max(1, calls), "kernel_ms_sstats": ss_ms / max(1, calls),
-           "max_rel_ll_delta_vs_reference": float(delta.max()),
-           "iters_equal_fraction": float(np.mean(iters == g["iters"]))}
-    if not args.no_cpu_baseline:
+           "launch_classes": len(corpus.plan()),
+           "max_rel_ll_delta_vs_reference": worst, "iters_equal_fraction": same / D_total}
+    if not args.no_cpu_baseline and job.rank == 0 and job.world == 1:
         rate, n, _ = cpu_baseline(alpha, eta, ptr, ids, cts, min(args.cpu_seconds, 6.0), 2000)
         out.update({"cpu_docs_per_s": rate, "cpu_sample_docs": n, "speedup": gpu_rate / rate})
     corpus.close()
@@ -498,62 +580,75 @@ def ap_extra(_capi, args):
     return out
 
 
-def nips_extra(_capi, args):
-    """BASELINE.json cfg 5 on one GPU: parsed/nips.88-05, K=500, 50 learning() iterations from the reference's
-    seeded start; E-step time / docs/s, joint log-likelihood and held-out per-token log-likelihood after 50
-    iterations against the reference's own trace (tests/golden/nips_trace_k500.npz)."""
+def nips_extra(job, args):
+    """BASELINE.json cfg 5: parsed/nips.88-05, K=500, 50 learning() iterations from the reference's seeded start,
+    documents sharded over the N ranks (one all-reduce of the K x V statistics per iteration); E-step time / docs/s,
+    the joint log-likelihood of EVERY iteration against the reference's own trace, and the held-out per-token
+    log-likelihood after 50 iterations (rank 0) against the reference's value (tests/golden/nips_trace_k500.npz)."""
+    from pylda_amd.corpus import shard_bounds
     from pylda_amd.variational_bayes import VariationalBayes
     g = np.load(os.path.join(ROOT, "tests", "golden", "nips_trace_k500.npz"))
     K, V = int(g["K"]), len(g["words"])
     ptr, ids, cts = g["doc_ptr"].astype(np.int64), g["term_id"].astype(np.int32), g["term_ct"].astype(np.int32)
     test = (g["test_doc_ptr"].astype(np.int64), g["test_term_id"].astype(np.int32), g["test_term_ct"].astype(np.int32))
-    np.random.seed(int(g["seed"]))
-    m = VariationalBayes()
-    m._verbose = False
-    m._initialize_parsed(ptr, ids, cts, V, K, 1.0 / K, 1.0 / V)      # eta: the seeded draw of variational_bayes.py:95
-    ctx = m._context()
     D, nnz = len(ptr) - 1, int(ptr[-1])
+    bounds = shard_bounds(ptr, job.world)
+    lo, hi = int(bounds[job.rank]), int(bounds[job.rank + 1])
+    np.random.seed(int(g["seed"]))
+    m = VariationalBayes(device=job.local_rank, process_group=job.group)
+    m._verbose = False
+    # eta: the seeded draw of variational_bayes.py:95 (the same on every rank)
+    m._initialize_parsed(ptr[lo:hi + 1] - ptr[lo], ids[ptr[lo]:ptr[hi]], cts[ptr[lo]:ptr[hi]], V, K, 1.0 / K, 1.0 / V)
+    ctx = m._context()
     n_iter = min(50, len(g["joint_ll"]))
-    m.learning()
+    trace = [m.learning()]
     ctx.synchronize()
     ctx.set_profiling(True)
     ctx.kernel_time()
+    job.barrier()
     t0 = time.perf_counter()
     for _ in range(n_iter - 1):
-        joint = m.learning()
-    ctx.synchronize()
-    elapsed = time.perf_counter() - t0
+        trace.append(m.learning())
+    job.barrier()
+    elapsed = job.reduce([time.perf_counter() - t0], "max")[0]
     doc_ms, ss_ms, calls = ctx.kernel_time()
     classes = m._train_corpus.plan()
     ctx.set_profiling(False)
     calls = max(1, calls)
-    wll, _ = m.e_step(test)
-    ref_joint = float(g["joint_ll"][n_iter - 1])
+    joint = trace[-1]
+    ref_trace = np.asarray(g["joint_ll"][:n_iter], dtype=np.float64)
+    trace_delta = float(np.max(np.abs(np.array(trace) - ref_trace) / np.abs(ref_trace)))
+    assert trace_delta < 1e-8, "nips K=500 joint log-likelihood trace differs from the reference's: %g" % trace_delta
     heldout = {int(it): v for it, v in g["heldout"]}
     tokens = int(g["test_tokens"])
-    B = algorithmic_bytes(nnz, D, K)
+    B = algorithmic_bytes(int(ptr[hi] - ptr[lo]), hi - lo, K)
     kernel_ms = (doc_ms + ss_ms) / calls
     for c in classes:
         c["kernel_ms"] /= calls
-    out = {"docs_per_s": D * (n_iter - 1) / elapsed, "ms_per_step": elapsed / (n_iter - 1) * 1e3, "iterations": n_iter,
-           "config": {"workload": "parsed/nips.88-05, K=500, train = first 2235 documents, test = last 248",
-                      "docs": D, "nnz": nnz, "K": K, "V": V},
+    out = {"docs_per_s": D * (n_iter - 1) / elapsed, "n_gpus": job.world, "ms_per_step": elapsed / (n_iter - 1) * 1e3,
+           "iterations": n_iter,
+           "config": {"workload": "parsed/nips.88-05, K=500, train = first 2235 documents (sharded by document), test = last 248",
+                      "docs": D, "nnz": nnz, "K": K, "V": V, "docs_rank0": hi - lo},
            "roofline": {"bound": "hbm", "achieved": B / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": B / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": kernel_ms,
                         "kernel_ms_documents": doc_ms / calls, "kernel_ms_sstats": ss_ms / calls,
                         "algorithmic_bytes": B, "launch_classes": classes,
-                        "note": "2235 workgroup-documents on 256 CUs: latency-bound, not a bandwidth measurement"},
-           "joint_log_likelihood": joint, "reference_joint_log_likelihood": ref_joint,
-           "joint_rel_delta": abs(joint - ref_joint) / abs(ref_joint),
-           "heldout_per_token_log_likelihood": wll / tokens}
-    if n_iter in heldout:
-        out["reference_heldout_per_token_log_likelihood"] = heldout[n_iter] / tokens
-        out["heldout_rel_delta"] = abs(wll - heldout[n_iter]) / abs(heldout[n_iter])
-    if not args.no_cpu_baseline:
-        rate, n, _ = cpu_baseline(m._alpha_alpha.copy(), m._eta.copy(), ptr, ids, cts, min(args.cpu_seconds, 10.0), 200)
-        out["cpu_baseline"] = {"value": rate, "unit": "docs/s", "cores": 1, "kind": "port",
-                               "sample": "first %d training documents, numpy/scipy restatement, single thread" % n}
-        out["speedup_vs_cpu"] = out["docs_per_s"] / rate
+                        "note": "rank 0's share of 2235 workgroup-documents on 256 CUs: latency-bound, not a bandwidth measurement"},
+           "joint_log_likelihood": joint, "reference_joint_log_likelihood": float(ref_trace[-1]),
+           "joint_rel_delta": abs(joint - ref_trace[-1]) / abs(ref_trace[-1]),
+           "joint_trace_max_rel_delta": trace_delta}
+    if job.rank == 0:
+        wll, _ = m.e_step(test)
+        out["heldout_per_token_log_likelihood"] = wll / tokens
+        if n_iter in heldout:
+            out["reference_heldout_per_token_log_likelihood"] = heldout[n_iter] / tokens
+            out["heldout_rel_delta"] = abs(wll - heldout[n_iter]) / abs(heldout[n_iter])
+        if not args.no_cpu_baseline and job.world == 1:
+            rate, n, _ = cpu_baseline(m._alpha_alpha.copy(), m._eta.copy(), ptr, ids, cts, min(args.cpu_seconds, 10.0), 200)
+            out["cpu_baseline"] = {"value": rate, "unit": "docs/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d training documents, numpy/scipy restatement, single thread" % n}
+            out["speedup_vs_cpu"] = out["docs_per_s"] / rate
+    job.barrier()
     release(m)
     return out
 

@@ -43,7 +43,19 @@ typedef enum pylda_status {
     PYLDA_ERR_STATE = -4    /* call sequence error (e.g. results before an e-step) */
 } pylda_status;
 
-/* Library version string, e.g. "pylda_hip 0.1 (gfx950)". */
+/* ABI version: bumped whenever an existing entry point changes its signature or meaning.
+ *   1  round-1 interface
+ *   2  pylda_parse_corpus gained doc_separator, pylda_kernel_time its third output,
+ *      pylda_set_stream(NULL) = HIP's null stream (pylda_use_own_stream restores the private one)
+ *   3  additions only: pylda_abi_version, pylda_mstep_enqueue / pylda_outer_device / pylda_allreduce_outer /
+ *      pylda_outer_fetch (one host wait per outer iteration), pylda_model_checkpoint, pylda_mark_time /
+ *      pylda_elapsed_ms, pylda_work_counters; pylda_set_alpha no longer waits for the stream
+ * A host compiled against another version must refuse to run: compare PYLDA_ABI_VERSION with
+ * pylda_abi_version() right after loading the library. */
+#define PYLDA_ABI_VERSION 3
+int pylda_abi_version(void);
+
+/* Library version string, e.g. "pylda_hip 0.3 (gfx950, abi 3)". */
 const char* pylda_version(void);
 
 /* Number of visible HIP devices (0 is a valid answer, not an error). */
@@ -165,6 +177,36 @@ int pylda_allreduce_doubles(pylda_ctx* ctx, double* values, int64_t n);
 int pylda_mstep(pylda_ctx* ctx, pylda_corpus* corpus, const double* beta_v,
                 double* topic_log_likelihood, double* alpha_ss_k);
 
+/* learning() (variational_bayes.py:239-261) with ONE host wait per outer iteration.  After pylda_estep (and the
+ * all-reduce of the sufficient statistics when there are several ranks):
+ *   pylda_mstep_enqueue   the device half of m_step (:218-235) - topic log-likelihood terms of the PRE-update eta,
+ *                         eta <- sstats + beta, alpha sufficient statistics from the gamma of `corpus` - plus a
+ *                         pack of every value the host half needs into one device vector; nothing is waited for;
+ *   pylda_outer_device    that vector (2K + 4 doubles) and how many of its LEADING elements are rank-local sums:
+ *                         [document log-likelihood (:214), #documents, documents redone in log space, 0,
+ *                          alpha sufficient statistics (K) (:232-233) | per-topic likelihood terms (K), replicated];
+ *                         a multi-rank host sums the leading *n_reduce elements over the ranks in place, on the
+ *                         context's stream (the Python class: torch.distributed; a C host: pylda_allreduce_outer);
+ *   pylda_outer_fetch     one device-to-host copy + the wait; any output pointer may be NULL. */
+int pylda_mstep_enqueue(pylda_ctx* ctx, pylda_corpus* corpus, const double* beta_v);
+void* pylda_outer_device(pylda_ctx* ctx, int64_t* n_reduce);
+int pylda_allreduce_outer(pylda_ctx* ctx);
+int pylda_outer_fetch(pylda_ctx* ctx, double* document_log_likelihood, double* number_of_documents,
+                      int64_t* logspace_documents, double* topic_log_likelihood, double* alpha_ss_k);
+
+/* Device-side model checkpoint: restore = 0 saves eta (the model; the counterpart of the reference's
+ * snapshot pickles, launch_train.py:203-204, without the trip through the host), restore = 1 puts the saved
+ * eta back.  Asynchronous on the context's stream.  bench.py uses it to time the same outer iterations
+ * repeatedly. */
+int pylda_model_checkpoint(pylda_ctx* ctx, int restore);
+
+/* Time stamps on the context's stream (4 slots): pylda_mark_time records an event NOW in stream order,
+ * pylda_elapsed_ms waits for slot_to and returns the device time between the two.  learning() uses them
+ * for the reference's "e_step and m_step ... finished in" line (variational_bayes.py:254) now that the
+ * host no longer waits between the two steps. */
+int pylda_mark_time(pylda_ctx* ctx, int slot);
+int pylda_elapsed_ms(pylda_ctx* ctx, int slot_from, int slot_to, double* ms);
+
 /* Profiling: when enabled, every pylda_estep brackets (HIP events on the launch
  * streams) its document kernels as a group, each launch class on its own, and
  * the sufficient-statistics pass (gather + finalize).  pylda_kernel_time
@@ -173,6 +215,10 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* corpus, const double* beta_v,
 int pylda_set_profiling(pylda_ctx* ctx, int enabled);
 int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, double* sstats_kernel_ms,
                       int64_t* estep_calls);
+/* With profiling enabled every pylda_estep also accumulates, on the device, the inner iterations its documents
+ * actually ran (sum_d I_d) and their terms (sum_d I_d N_d: 4 K flops each, :177-185).  Returns and resets them
+ * (synchronises). */
+int pylda_work_counters(pylda_ctx* ctx, double* inner_iterations, double* inner_iteration_terms);
 
 /* The launch schedule of a corpus: documents are bucketed by distinct-term
  * count into launch classes (one kernel instantiation each; the classes of one

@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 
+ABI_VERSION = 3          # == PYLDA_ABI_VERSION of include/pylda_hip.h (checked at load time)
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpylda_hip.so")
 _lib = None
 
@@ -20,6 +21,7 @@ _vp = ctypes.c_void_p
 # name -> (restype, argtypes); must list every symbol include/pylda_hip.h declares
 SIGNATURES = {
     "pylda_version": (ctypes.c_char_p, []),
+    "pylda_abi_version": (ctypes.c_int, []),
     "pylda_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "pylda_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
     "pylda_destroy": (None, [_vp]),
@@ -54,6 +56,14 @@ SIGNATURES = {
     "pylda_allreduce_sstats": (ctypes.c_int, [_vp]),
     "pylda_allreduce_doubles": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int64]),
     "pylda_mstep": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, _c_double_p]),
+    "pylda_mstep_enqueue": (ctypes.c_int, [_vp, _vp, _c_double_p]),
+    "pylda_outer_device": (_vp, [_vp, _c_int64_p]),
+    "pylda_allreduce_outer": (ctypes.c_int, [_vp]),
+    "pylda_outer_fetch": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_int64_p, _c_double_p, _c_double_p]),
+    "pylda_model_checkpoint": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "pylda_mark_time": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "pylda_elapsed_ms": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _c_double_p]),
+    "pylda_work_counters": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
     "pylda_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pylda_kernel_time": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_int64_p]),
     "pylda_corpus_layout": (ctypes.c_int64, [_vp, ctypes.c_char_p]),
@@ -110,6 +120,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError => ABI/header mismatch, fail loudly
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.pylda_abi_version() != ABI_VERSION:
+        raise RuntimeError("pylda_amd: %s implements ABI %d, this binding was written for ABI %d - rebuild it "
+                           "(python -m pylda_amd.build --force)" % (_LIB_PATH, lib.pylda_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -308,6 +321,46 @@ class Context(object):
         self._check(self._lib.pylda_mstep(self._h, corpus._h if corpus is not None else None,
                                           _dp(beta), ctypes.byref(tll), _dp(ass)))
         return tll.value, ass
+
+    def mstep_enqueue(self, corpus, beta):
+        """The device half of m_step, nothing waited for (see outer_fetch)."""
+        beta = _f64(beta, (self.V,), "beta")
+        self._check(self._lib.pylda_mstep_enqueue(self._h, corpus._h, _dp(beta)))
+
+    def outer_device(self):
+        """(device pointer, elements, leading elements that are rank-local sums) of the packed outer-iteration values."""
+        n = ctypes.c_int64(0)
+        ptr = self._lib.pylda_outer_device(self._h, ctypes.byref(n))
+        return int(ptr or 0), 2 * self.K + 4, int(n.value)
+
+    def allreduce_outer(self):
+        self._check(self._lib.pylda_allreduce_outer(self._h))
+
+    def outer_fetch(self):
+        """(document_log_likelihood, number_of_documents, logspace_documents, topic_log_likelihood, alpha_ss):
+        the one host wait of an outer iteration."""
+        ll, nd, tll, nlog = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+        ass = np.empty(self.K, dtype=np.float64)
+        self._check(self._lib.pylda_outer_fetch(self._h, ctypes.byref(ll), ctypes.byref(nd), ctypes.byref(nlog),
+                                                ctypes.byref(tll), _dp(ass)))
+        return ll.value, int(round(nd.value)), nlog.value, tll.value, ass
+
+    def model_checkpoint(self, restore=False):
+        self._check(self._lib.pylda_model_checkpoint(self._h, 1 if restore else 0))
+
+    def mark_time(self, slot):
+        self._check(self._lib.pylda_mark_time(self._h, int(slot)))
+
+    def elapsed_ms(self, slot_from, slot_to):
+        ms = ctypes.c_double(0)
+        self._check(self._lib.pylda_elapsed_ms(self._h, int(slot_from), int(slot_to), ctypes.byref(ms)))
+        return ms.value
+
+    def work_counters(self):
+        """(sum_d I_d, sum_d I_d N_d) of the profiled E-steps since the last call."""
+        a, b = ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.pylda_work_counters(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     # ---- device-resident interop ----
     def sstats_elements(self):

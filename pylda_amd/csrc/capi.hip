@@ -101,6 +101,17 @@ struct pylda_ctx {
     double beta_sum = 0.0, beta_lgamma_sum = 0.0;
 
     std::vector<double> h_alpha;
+    // pinned host staging (one allocation): two alpha slots (K each) + the outer-iteration read-back (2K + 8)
+    double* h_pin = nullptr;
+    hipEvent_t alpha_event[2] = {nullptr, nullptr};
+    bool alpha_event_used[2] = {false, false};
+    int alpha_slot = 0;
+    double* d_outer = nullptr;      // [doc ll, #documents, log-space documents, 0, alpha ss (K) | per-topic ll (K)]
+    bool outer_ready = false;
+    bool outer_has_alpha_ss = false;
+    double* d_eta_ckpt = nullptr;   // pylda_model_checkpoint
+    double* d_work = nullptr;       // profiling: [sum_d I_d, sum_d I_d N_d] accumulated over E-steps
+    hipEvent_t mark_event[4] = {nullptr, nullptr, nullptr, nullptr};
     void* comm = nullptr;           // RCCL communicator of pylda_comm_init (multi-GPU through the C ABI)
     int comm_world = 1;
     double* d_comm_small = nullptr; // staging buffer of pylda_allreduce_doubles
@@ -111,6 +122,7 @@ struct pylda_ctx {
     int quilt12 = 0;
     int gather_rows = 2;            // 0: 64-topic chunks; 1: whole rows (ldk 64 / 128 / 256); 2: + postings in bulk (ldk 128 / 256)
     int gather_blocks = -1;         // document blocks of the gather: -1 automatic, 0 / 1 off, n forced (multiple of 8)
+    int quad_tune = 0;              // A/B: start delay / priority of the second co-resident workgroup (estep_quad.h)
     int lds_pad = 0;                // A/B: extra dynamic LDS per quad workgroup (forces one workgroup per CU)
     int quad = 1;                   // register + LDS tile kernel (estep_quad.h) for table strides 128 / 256, N <= 208
     int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
@@ -803,7 +815,8 @@ void drain_events(pylda_ctx* ctx)
 
 extern "C" {
 
-const char* pylda_version(void) { return "pylda_hip 0.1 (gfx950)"; }
+const char* pylda_version(void) { return "pylda_hip 0.3 (gfx950, abi 3)"; }
+int pylda_abi_version(void) { return PYLDA_ABI_VERSION; }
 
 int pylda_device_count(int* count)
 {
@@ -885,6 +898,13 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     CREATE_TRY(dev_alloc(ctx, &ctx->d_alpha, (size_t)K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_small, (size_t)(4 * K + 16)));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_partial, (size_t)1024 * K));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_outer, (size_t)(2 * K + 8)));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_work, (size_t)2));
+    CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_work, 0, 2 * sizeof(double), ctx->stream), "hipMemsetAsync"));
+    CREATE_TRY(hip_ok(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), (size_t)(4 * K + 8) * sizeof(double), hipHostMallocDefault),
+                      "hipHostMalloc"));
+    for (int i = 0; i < 2; ++i)
+        CREATE_TRY(hip_ok(hipEventCreateWithFlags(&ctx->alpha_event[i], hipEventDisableTiming), "hipEventCreate"));
     CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_sstats, 0, wk * sizeof(double), ctx->stream),
                       "hipMemsetAsync"));
 #undef CREATE_TRY
@@ -904,7 +924,12 @@ void pylda_destroy(pylda_ctx* ctx)
     dev_free(ctx->d_eta); dev_free(ctx->d_elog); dev_free(ctx->d_expElog); dev_free(ctx->d_expElog_elog); dev_free(ctx->d_sstats);
     dev_free(ctx->d_kv_scratch); dev_free(ctx->d_shift); dev_free(ctx->d_beta);
     dev_free(ctx->d_psi_rowsum); dev_free(ctx->d_topic_lse); dev_free(ctx->d_alpha);
-    dev_free(ctx->d_small); dev_free(ctx->d_partial);
+    dev_free(ctx->d_small); dev_free(ctx->d_partial); dev_free(ctx->d_outer); dev_free(ctx->d_work); dev_free(ctx->d_eta_ckpt);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->alpha_event[i]) (void)hipEventDestroy(ctx->alpha_event[i]);
+    for (hipEvent_t e : ctx->mark_event)
+        if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < pylda_ctx::kAux; ++i) {
         if (ctx->aux_stream[i]) { (void)hipStreamSynchronize(ctx->aux_stream[i]); (void)hipStreamDestroy(ctx->aux_stream[i]); }
         if (ctx->join_event[i]) (void)hipEventDestroy(ctx->join_event[i]);
@@ -959,6 +984,8 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     } else if (!strcmp(name, "quilt_odd")) {
         ctx->quilt_odd = value != 0;
         ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "quad_tune")) {
+        ctx->quad_tune = (int)value;
     } else if (!strcmp(name, "lds_pad")) {
         ctx->lds_pad = (int)value;
     } else if (!strcmp(name, "quad")) {
@@ -1131,9 +1158,16 @@ int pylda_set_alpha(pylda_ctx* ctx, const double* alpha_k)
             return fail(ctx, PYLDA_ERR_INVALID, "set_alpha: alpha[%d]=%g is not positive", k, alpha_k[k]);
     ctx->h_alpha.assign(alpha_k, alpha_k + ctx->K);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_alpha, ctx->h_alpha.data(), (size_t)ctx->K * sizeof(double),
-                                hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // no stream wait: the values go through one of two pinned slots (the copy is ordered on the stream behind the
+    // kernels still reading the previous alpha); a slot is reused only when its last copy has left it
+    const int slot = ctx->alpha_slot;
+    ctx->alpha_slot ^= 1;
+    if (ctx->alpha_event_used[slot]) HIP_TRY(ctx, hipEventSynchronize(ctx->alpha_event[slot]));
+    double* pin = ctx->h_pin + (size_t)slot * ctx->K;
+    memcpy(pin, alpha_k, (size_t)ctx->K * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_alpha, pin, (size_t)ctx->K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->alpha_event[slot], ctx->stream));
+    ctx->alpha_event_used[slot] = true;
     ctx->have_alpha = true;
     return PYLDA_OK;
 }
@@ -1184,6 +1218,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     p.tfinal = c->d_tfinal;
     p.rfinal = c->d_rfinal;
     p.status = c->d_status;
+    p.tune = ctx->quad_tune;
 
     {
         const double span = tol * K;
@@ -1258,6 +1293,8 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         hipLaunchKernelGGL(doc_terms_kernel, dim3((unsigned)((c->D + 3) / 4)), dim3(256), 0, ctx->stream, p, c->D);
     close_bracket(doc_bracket, ctx->stream);
     if (ctx->profiling) ctx->estep_calls += 1;
+    if (ctx->profiling && c->D > 0)       // inner iterations actually executed, for the fp64 roofline and doc-iterations/s
+        hipLaunchKernelGGL(work_count_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_iters, c->d_doc_ptr, c->D, ctx->d_work);
 
     // sufficient statistics (:207): gather pass over the postings, no atomics
     if (!heldout) {
@@ -1413,15 +1450,15 @@ int pylda_mark_device_state(pylda_ctx* ctx, int have_eta, int have_sstats)
     return PYLDA_OK;
 }
 
-int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* topic_log_likelihood,
-                double* alpha_ss_k)
+namespace {
+// The device half of m_step (:218-235): kernels only, nothing is read back.
+int enqueue_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, bool want_alpha_ss, const char* who)
 {
-    if (!ctx) return PYLDA_ERR_INVALID;
-    if (!beta_v) return fail(ctx, PYLDA_ERR_INVALID, "mstep: beta is NULL");
+    if (!beta_v) return fail(ctx, PYLDA_ERR_INVALID, "%s: beta is NULL", who);
     if (!ctx->have_eta || !ctx->have_sstats)
-        return fail(ctx, PYLDA_ERR_STATE, "mstep: needs eta and the sufficient statistics of a training E-step");
-    if (alpha_ss_k && (!c || c->ctx != ctx || !c->estep_done))
-        return fail(ctx, PYLDA_ERR_STATE, "mstep: alpha statistics need the corpus of the last E-step");
+        return fail(ctx, PYLDA_ERR_STATE, "%s: needs eta and the sufficient statistics of a training E-step", who);
+    if (want_alpha_ss && (!c || c->ctx != ctx || !c->estep_done))
+        return fail(ctx, PYLDA_ERR_STATE, "%s: alpha statistics need the corpus of the last E-step", who);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int K = ctx->K, V = ctx->V;
     // beta is constant over a run: its lgamma sums (V host lgamma calls) and the device copy are
@@ -1429,7 +1466,7 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* t
     if (ctx->h_beta.size() != (size_t)V || memcmp(ctx->h_beta.data(), beta_v, (size_t)V * sizeof(double)) != 0) {
         double bsum = 0.0, blg = 0.0;
         for (int v = 0; v < V; ++v) {
-            if (!(beta_v[v] > 0.0)) return fail(ctx, PYLDA_ERR_INVALID, "mstep: beta[%d]=%g", v, beta_v[v]);
+            if (!(beta_v[v] > 0.0)) return fail(ctx, PYLDA_ERR_INVALID, "%s: beta[%d]=%g", who, v, beta_v[v]);
             bsum += beta_v[v];
             blg += std::lgamma(beta_v[v]);
         }
@@ -1440,7 +1477,6 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* t
         ctx->beta_sum = bsum;
         ctx->beta_lgamma_sum = blg;
     }
-    const double bsum = ctx->beta_sum, blg = ctx->beta_lgamma_sum;
     double* d_per_topic = ctx->d_small;          // K
     double* d_alpha_ss = ctx->d_small + K;       // K
     hipLaunchKernelGGL(mstep_topic_ll_kernel, dim3(K, kTopicChunks), dim3(256), 0, ctx->stream, ctx->d_eta, K, V,
@@ -1449,23 +1485,146 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* t
                        d_per_topic);
     hipLaunchKernelGGL(mstep_update_eta_kernel, dim3((K + 31) / 32, (V + 31) / 32), dim3(256), 0, ctx->stream,
                        ctx->d_sstats, ctx->d_beta, K, V, ctx->ldk, ctx->d_eta);                                               // :226
-    int nblocks = 0;
-    if (alpha_ss_k) {
-        nblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (c->D + 3) / 4));     // (ctx->d_partial holds 1024 rows)
+    if (want_alpha_ss) {
+        const int nblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (c->D + 3) / 4));     // (ctx->d_partial holds 1024 rows)
         hipLaunchKernelGGL(mstep_alpha_ss_kernel, dim3(nblocks), dim3(256), (size_t)4 * K * sizeof(double),
                            ctx->stream, c->d_gamma, c->D, K, ctx->d_partial);                                       // :232
         hipLaunchKernelGGL(column_sum_kernel, dim3((K + 63) / 64), dim3(256), 0, ctx->stream, ctx->d_partial,
                            nblocks, K, d_alpha_ss);                                                                 // :233
     }
     HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+double topic_ll_from(const pylda_ctx* ctx, const double* per_topic)
+{
+    double ll = ctx->K * (std::lgamma(ctx->beta_sum) - ctx->beta_lgamma_sum);                                       // :222
+    for (int k = 0; k < ctx->K; ++k) ll += per_topic[k];
+    return ll;
+}
+}  // namespace
+
+int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* topic_log_likelihood,
+                double* alpha_ss_k)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    const int rc = enqueue_mstep(ctx, c, beta_v, alpha_ss_k != nullptr, "mstep");
+    if (rc != PYLDA_OK) return rc;
+    const int K = ctx->K;
     std::vector<double> per_topic((size_t)K);
-    HIP_TRY(ctx, hipMemcpyAsync(per_topic.data(), d_per_topic, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(per_topic.data(), ctx->d_small, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (alpha_ss_k)
-        HIP_TRY(ctx, hipMemcpyAsync(alpha_ss_k, d_alpha_ss, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(alpha_ss_k, ctx->d_small + K, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    double ll = K * (std::lgamma(bsum) - blg);                                                                      // :222
-    for (int k = 0; k < K; ++k) ll += per_topic[k];
-    if (topic_log_likelihood) *topic_log_likelihood = ll;
+    if (topic_log_likelihood) *topic_log_likelihood = topic_ll_from(ctx, per_topic.data());
+    return PYLDA_OK;
+}
+
+int pylda_mstep_enqueue(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!c || c->ctx != ctx || !c->estep_done || c->last_heldout)
+        return fail(ctx, PYLDA_ERR_STATE, "mstep_enqueue: needs the corpus of the last training-mode E-step");
+    const int rc = enqueue_mstep(ctx, c, beta_v, true, "mstep_enqueue");
+    if (rc != PYLDA_OK) return rc;
+    const int K = ctx->K;
+    hipLaunchKernelGGL(outer_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, c->d_scalars, c->d_flag_count,
+                       c->last_doc_values ? 1 : 0, (double)c->D, ctx->d_small + K, ctx->d_small, K, ctx->d_outer);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->outer_ready = true;
+    return PYLDA_OK;
+}
+
+void* pylda_outer_device(pylda_ctx* ctx, int64_t* n_reduce)
+{
+    if (!ctx) return nullptr;
+    if (n_reduce) *n_reduce = ctx->K + 4;
+    return ctx->d_outer;
+}
+
+int pylda_allreduce_outer(pylda_ctx* ctx)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!ctx->comm) return fail(ctx, PYLDA_ERR_STATE, "allreduce_outer: pylda_comm_init has not been called");
+    if (!ctx->outer_ready) return fail(ctx, PYLDA_ERR_STATE, "allreduce_outer: pylda_mstep_enqueue has not run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    const int rc = pylda::comm_allreduce_sum_f64(ctx->comm, ctx->d_outer, (size_t)ctx->K + 4, ctx->stream, &err);
+    return rc == PYLDA_OK ? rc : fail(ctx, rc, "allreduce_outer: %s", err.c_str());
+}
+
+int pylda_outer_fetch(pylda_ctx* ctx, double* document_log_likelihood, double* number_of_documents,
+                      int64_t* logspace_documents, double* topic_log_likelihood, double* alpha_ss_k)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!ctx->outer_ready) return fail(ctx, PYLDA_ERR_STATE, "outer_fetch: pylda_mstep_enqueue has not run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int K = ctx->K;
+    double* host = ctx->h_pin + (size_t)2 * K;
+    HIP_TRY(ctx, hipMemcpyAsync(host, ctx->d_outer, (size_t)(2 * K + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the ONE wait of an outer iteration
+    ctx->outer_ready = false;
+    if (document_log_likelihood) *document_log_likelihood = host[0];
+    if (number_of_documents) *number_of_documents = host[1];
+    if (logspace_documents) *logspace_documents = (int64_t)std::llround(host[2]);
+    if (alpha_ss_k) memcpy(alpha_ss_k, host + 4, (size_t)K * sizeof(double));
+    if (topic_log_likelihood) *topic_log_likelihood = topic_ll_from(ctx, host + 4 + K);
+    return PYLDA_OK;
+}
+
+int pylda_model_checkpoint(pylda_ctx* ctx, int restore)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->K * ctx->V * sizeof(double);
+    if (!restore) {
+        if (!ctx->have_eta) return fail(ctx, PYLDA_ERR_STATE, "model_checkpoint: eta was never set");
+        if (!ctx->d_eta_ckpt) {
+            const int rc = dev_alloc(ctx, &ctx->d_eta_ckpt, (size_t)ctx->K * ctx->V);
+            if (rc != PYLDA_OK) return rc;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eta_ckpt, ctx->d_eta, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        if (!ctx->d_eta_ckpt) return fail(ctx, PYLDA_ERR_STATE, "model_checkpoint: nothing was saved");
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eta, ctx->d_eta_ckpt, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->have_eta = true;
+    }
+    return PYLDA_OK;
+}
+
+int pylda_mark_time(pylda_ctx* ctx, int slot)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (slot < 0 || slot >= 4) return fail(ctx, PYLDA_ERR_INVALID, "mark_time: slot %d", slot);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->mark_event[slot]) HIP_TRY(ctx, hipEventCreate(&ctx->mark_event[slot]));
+    HIP_TRY(ctx, hipEventRecord(ctx->mark_event[slot], ctx->stream));
+    return PYLDA_OK;
+}
+
+int pylda_elapsed_ms(pylda_ctx* ctx, int slot_from, int slot_to, double* ms)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (slot_from < 0 || slot_from >= 4 || slot_to < 0 || slot_to >= 4 || !ms || !ctx->mark_event[slot_from] || !ctx->mark_event[slot_to])
+        return fail(ctx, PYLDA_ERR_INVALID, "elapsed_ms: slots %d, %d", slot_from, slot_to);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->mark_event[slot_to]));
+    float f = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&f, ctx->mark_event[slot_from], ctx->mark_event[slot_to]));
+    *ms = f;
+    return PYLDA_OK;
+}
+
+int pylda_work_counters(pylda_ctx* ctx, double* inner_iterations, double* inner_iteration_terms)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double w[2] = {0.0, 0.0};
+    HIP_TRY(ctx, hipMemcpyAsync(w, ctx->d_work, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof w, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (inner_iterations) *inner_iterations = w[0];
+    if (inner_iteration_terms) *inner_iteration_terms = w[1];
     return PYLDA_OK;
 }
 

@@ -121,4 +121,45 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const double* __restric
     if (grp == 0 && k < K) out[k] = (part[0][kk] + part[1][kk]) + (part[2][kk] + part[3][kk]);
 }
 
+// Everything the host half of learning() reads after one outer iteration (:244-252), packed for ONE copy:
+//   out[0] document log-likelihood (training fast path: the corpus-level entropy term subtracted here, exactly the
+//          host's former `sc[0] -= sc[2]`), out[1] #documents, out[2] documents redone in log space, out[3] 0,
+//   out[4 .. 4+K) alpha sufficient statistics        - these K + 4 values are summed over the ranks -
+//   out[4+K .. 4+2K) per-topic terms of the topic log-likelihood (:224; identical on every rank)
+__global__ __launch_bounds__(256) void outer_pack_kernel(const double* __restrict__ scalars, const int32_t* __restrict__ flag_count,
+                                                         int doc_values, double n_docs, const double* __restrict__ alpha_ss,
+                                                         const double* __restrict__ per_topic, int K, double* __restrict__ out)
+{
+    if (threadIdx.x == 0) {
+        out[0] = doc_values ? scalars[0] : scalars[0] - scalars[2];
+        out[1] = n_docs;
+        out[2] = (double)flag_count[0];
+        out[3] = 0.0;
+    }
+    for (int k = threadIdx.x; k < K; k += 256) {
+        out[4 + k] = alpha_ss[k];
+        out[4 + K + k] = per_topic[k];
+    }
+}
+
+// Profiling: work[0] += sum_d I_d, work[1] += sum_d I_d N_d (inner iterations executed, and their terms) - single
+// workgroup, so the accumulation over E-steps needs no atomics.
+__global__ __launch_bounds__(1024) void work_count_kernel(const int32_t* __restrict__ iters, const int64_t* __restrict__ doc_ptr,
+                                                          int64_t D, double* __restrict__ work)
+{
+    __shared__ double scratch[16];
+    double a = 0.0, b = 0.0;
+    for (int64_t d = threadIdx.x; d < D; d += 1024) {
+        const double it = (double)iters[d];
+        a += it;
+        b += it * (double)(doc_ptr[d + 1] - doc_ptr[d]);
+    }
+    a = block_sum<1024>(a, scratch);
+    b = block_sum<1024>(b, scratch);
+    if (threadIdx.x == 0) {
+        work[0] += a;
+        work[1] += b;
+    }
+}
+
 }  // namespace pylda

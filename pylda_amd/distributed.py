@@ -74,6 +74,27 @@ def allreduce_sstats(ctx, group=None):
     return t
 
 
+def allreduce_outer(ctx, group=None):
+    """In-place sum over the ranks of the rank-local part of the packed outer-iteration values
+    (pylda_outer_device: document log-likelihood, #documents, log-space documents, alpha statistics),
+    on the context's stream between pylda_mstep_enqueue and pylda_outer_fetch: no host wait with RCCL."""
+    import torch
+    import torch.distributed as dist
+    ptr, _, n_reduce = ctx.outer_device()
+    t = device_tensor(ptr, (n_reduce,), torch.device("cuda", ctx.device))
+    with _stream_scope(ctx):
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        else:
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(host)
+            torch.cuda.current_stream(ctx.device).synchronize()
+        if getattr(ctx, "_torch_stream", None) is None:
+            torch.cuda.current_stream(ctx.device).synchronize()
+    return t
+
+
 def allreduce_small(group, document_log_likelihood, number_of_documents, alpha_ss, device=None):
     """Sum (LL, D, alpha sufficient statistics) over ranks; returns python/numpy values."""
     import torch

@@ -266,7 +266,12 @@ class VariationalBayes(Inferencer):
         self._push_model()
         corpus = self._training_corpus()
 
-        clock_e_step = time.time()
+        # Everything is enqueued before anything is read back: E-step -> [all-reduce] -> device M-step -> pack ->
+        # [all-reduce of the packed rank-local values] -> ONE copy + wait (pylda_outer_fetch).  The reference's two
+        # wall-clock spans (:241-250) are therefore device time between stream marks, not host time.
+        timed = self._verbose
+        if timed:
+            ctx.mark_time(0)
         ctx.estep(corpus, 50, 1e-6, False)
         self._reference_side_effects(corpus.D)
         group = self._process_group
@@ -274,25 +279,23 @@ class VariationalBayes(Inferencer):
             from pylda_amd import distributed
             distributed.allreduce_sstats(ctx, group)
         self._gamma_host_stale = self._gamma_on_device = True
-        clock_e_step = time.time() - clock_e_step
-
-        clock_m_step = time.time()
-        # the M-step kernels are queued behind the E-step before anything is read back: one wait per
-        # outer iteration instead of two (the likelihood scalars of the E-step are not touched by it)
-        topic_log_likelihood, alpha_sufficient_statistics = ctx.mstep(corpus, self._alpha_beta)
-        document_log_likelihood, _, _ = ctx.estep_results(corpus)
-        self._eta_device_newer = True
-        number_of_documents = self._number_of_documents
+        if timed:
+            ctx.mark_time(1)
+        ctx.mstep_enqueue(corpus, self._alpha_beta)
         if group is not None:
-            from pylda_amd import distributed
-            document_log_likelihood, number_of_documents, alpha_sufficient_statistics = \
-                distributed.allreduce_small(group, document_log_likelihood,
-                                            self._number_of_documents, alpha_sufficient_statistics)
+            distributed.allreduce_outer(ctx, group)
+        if timed:
+            ctx.mark_time(2)
+        document_log_likelihood, number_of_documents, _, topic_log_likelihood, alpha_sufficient_statistics = \
+            ctx.outer_fetch()
+        self._eta_device_newer = True
+        clock_e_step = ctx.elapsed_ms(0, 1) * 1e-3 if timed else 0.0
+        clock_m_step = time.time()
         if self._hyper_parameter_optimize_interval > 0 and \
                 self._counter % self._hyper_parameter_optimize_interval == 0:
             self.optimize_hyperparameters(alpha_sufficient_statistics,
                                           number_of_documents=number_of_documents)
-        clock_m_step = time.time() - clock_m_step
+        clock_m_step = time.time() - clock_m_step + (ctx.elapsed_ms(1, 2) * 1e-3 if timed else 0.0)
 
         joint_log_likelihood = document_log_likelihood + topic_log_likelihood
         if self._verbose:
