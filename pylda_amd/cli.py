@@ -29,7 +29,10 @@ TRAIN_FLAGS = (
     ("alpha_alpha", float, -1, "hyper-parameter for Dirichlet distribution of topics [1.0/number_of_topics]"),
     ("alpha_beta", float, -1, "hyper-parameter for Dirichlet distribution of vocabulary [1.0/number_of_types]"),
     ("inference_mode", int, 2, "inference mode [2: variational bayes - the only engine here]"),
-    ("device", int, 0, "GPU index [0]"),
+    ("device", int, 0, "GPU index [0] (one process; with --gpus N rank r runs on GPU r)"),
+    ("gpus", int, 1, "GPUs of this node to shard the documents over [1]: re-executes itself under "
+                     "torch.distributed.run, one rank per GPU, one RCCL all-reduce of the K x V statistics per iteration"),
+    ("share_gpu", int, 0, "test mode [0]: 1 = all ranks on GPU 0, exchange over gloo (RCCL refuses two ranks per device)"),
 )
 TEST_FLAGS = (
     ("input_directory", str, None, "input directory [None]"),
@@ -69,6 +72,13 @@ def train_main(argv=None):
         sys.stderr.write("error: pylda_amd implements inference mode 2 (variational bayes) only, got %d...\n"
                          % opt.inference_mode)
         return 2
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # invoked as the reference's one-process command: become the launcher, one rank per GPU
+        os.execv(sys.executable, _launcher_argv(opt.gpus, sys.argv[1:] if argv is None else list(argv)))
+    rank, world, device, group = _join_ranks(opt)
+    seed = os.environ.get("PYLDA_SEED")      # the reference has no seed flag (numpy's global RNG, unseeded): reproducible runs
+    if rank != 0:
+        sys.stdout = open(os.devnull, "w")    # one copy of the reference's console output
     source = opt.input_directory.rstrip("/")
     corpus_name = os.path.basename(source)
     documents = _lines(os.path.join(source, "train.dat"))
@@ -83,27 +93,118 @@ def train_main(argv=None):
     run = "%s-lda-I%d-S%d-K%d-aa%f-ab%f-im%d/" % (stamp, opt.training_iterations, opt.snapshot_interval,
                                                   topics, prior_topics, prior_words, opt.inference_mode)
     run_dir = os.path.join(opt.output_directory, corpus_name, run)
-    os.makedirs(os.path.abspath(run_dir))
+    if rank == 0:
+        os.makedirs(os.path.abspath(run_dir))
     settings = (("input_directory", source), ("corpus_name", corpus_name),
                 ("training_iterations", "%d" % opt.training_iterations),
                 ("snapshot_interval", str(opt.snapshot_interval)), ("number_of_topics", str(topics)),
                 ("alpha_alpha", str(prior_topics)), ("alpha_beta", str(prior_words)),
                 ("inference_mode", "%d" % opt.inference_mode))
-    with open(run_dir + "option.txt", "w") as out:
-        out.writelines("%s=%s\n" % pair for pair in settings)
+    if rank == 0:
+        with open(run_dir + "option.txt", "w") as out:
+            out.writelines("%s=%s\n" % pair for pair in settings)
     _banner((("output_directory", run_dir),) + settings[:1] + settings[1:])
 
     from pylda_amd.variational_bayes import VariationalBayes
-    engine = VariationalBayes(device=opt.device)
+    engine = VariationalBayes(device=device, process_group=group)
+    if seed is not None:
+        numpy.random.seed(int(seed))
     engine._initialize(documents, vocabulary, topics, prior_topics, prior_words)
+    if group is not None:
+        _shard_engine(engine, group, rank, world)
     for _ in range(opt.training_iterations):
         engine.learning()
         if engine._counter % opt.snapshot_interval == 0:
-            engine.export_beta("%sexp_beta-%d" % (run_dir, engine._counter))
-            engine.export_gamma("%sexp_gamma-%d" % (run_dir, engine._counter))
-    with open(os.path.join(run_dir, "model-%d" % engine._counter), "wb") as out:
-        pickle.dump(engine, out)
+            whole = _whole_model(engine, group, rank, world)
+            if rank == 0:
+                whole.export_beta("%sexp_beta-%d" % (run_dir, engine._counter))
+                whole.export_gamma("%sexp_gamma-%d" % (run_dir, engine._counter))
+    whole = _whole_model(engine, group, rank, world)
+    if rank == 0:
+        with open(os.path.join(run_dir, "model-%d" % engine._counter), "wb") as out:
+            pickle.dump(whole, out)
+    if group is not None:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
+
+
+def _launcher_argv(gpus, argv):
+    """`python -m pylda_amd.launch_train ... --gpus N` as N ranks of this node (rendezvous on 127.0.0.1)."""
+    import socket
+    probe = socket.socket()
+    probe.bind(("127.0.0.1", 0))
+    port = probe.getsockname()[1]
+    probe.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "pylda_amd.launch_train"] + list(argv)
+
+
+def _join_ranks(opt):
+    """(rank, world, device, process group) of a --gpus N run; (0, 1, --device, None) otherwise."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if opt.gpus <= 1 or world <= 1:
+        return 0, 1, opt.device, None
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"])
+    device = 0 if opt.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if opt.share_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    return rank, world, device, dist.group.WORLD
+
+
+def _host_group():
+    """A gloo group next to the RCCL one, for the host-side object exchanges (eta of the start, gamma for exports)."""
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo":
+        return dist.group.WORLD
+    if not hasattr(_host_group, "group"):
+        _host_group.group = dist.new_group(backend="gloo")
+    return _host_group.group
+
+
+def _shard_engine(engine, group, rank, world):
+    """Every rank parsed the whole corpus and drew its own eta (:95, unseeded in the reference): keep rank 0's
+    draw everywhere, and this rank's contiguous nnz-balanced range of the documents."""
+    import torch
+    import torch.distributed as dist
+    from pylda_amd.corpus import shard_csr
+    eta = torch.from_numpy(numpy.ascontiguousarray(engine._eta))
+    dist.broadcast(eta, src=0, group=_host_group())
+    engine._eta = eta.numpy()
+    engine._whole_csr = engine._train_csr
+    doc_ptr, term_id, term_ct, (lo, hi) = shard_csr(*engine._train_csr, world, rank)
+    engine._train_csr = (doc_ptr, term_id, term_ct)
+    engine._parsed_lists = None
+    engine._number_of_documents = hi - lo
+    engine._train_corpus = None
+
+
+def _whole_model(engine, group, rank, world):
+    """The engine the exporters and the snapshot pickle see: at one rank the engine itself; at several, on rank 0, a
+    copy that holds the WHOLE corpus and the gamma rows of every rank in document order (the shards are contiguous)."""
+    if group is None:
+        return engine
+    import copy
+    import torch.distributed as dist
+    rows = [None] * world if rank == 0 else None
+    dist.gather_object(numpy.asarray(engine._gamma), rows, dst=0, group=_host_group())
+    if rank != 0:
+        return None
+    whole = copy.copy(engine)
+    whole.__dict__.update(engine.__getstate__())          # host copies only, no device handles
+    whole._gamma_host = numpy.concatenate(rows, axis=0)
+    whole._train_csr = engine._whole_csr
+    whole._parsed_lists = None
+    whole._number_of_documents = len(engine._whole_csr[0]) - 1
+    whole.__dict__.pop("_whole_csr", None)
+    return whole
 
 
 def evaluate_snapshot(snapshot_path, test_documents, gamma_path):

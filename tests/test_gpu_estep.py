@@ -38,11 +38,15 @@ def run(capi, alpha, eta, ptr, tid, tct, heldout=False, max_iter=50, tol=1e-6, o
     return out
 
 
-def check_against(out, ref_gamma, ref_ll, ref_iters, ll_key="doc_ll", min_same=0.995):
+def check_against(out, ref_gamma, ref_ll, ref_iters, ll_key="doc_ll", min_same=1.0):
     same = out["iters"] == ref_iters
-    # drift stays visible in the log (pytest -s / failure report): how many documents sit on the threshold
-    print("inner-iteration counts: %d of %d documents differ from the reference (allowed %.1f %%)"
-          % ((~same).sum(), same.size, 100.0 * (1.0 - min_same)))
+    # the stop test (:187-189) must fall on the same inner iteration as the reference's for EVERY document of the
+    # fixed-seed cases (tools/fuzz_parity.py: no flip in 90 000 random documents either); the first one that does
+    # not is named
+    if not same.all():
+        d = int(np.nonzero(~same)[0][0])
+        print("inner-iteration counts differ on %d of %d documents; first: document %d ran %d, reference %d"
+              % ((~same).sum(), same.size, d, out["iters"][d], ref_iters[d]))
     assert np.mean(same) >= min_same, "inner-iteration counts differ on %d documents" % (~same).sum()
     assert rel_err(out["gamma"][same], ref_gamma[same]) < GAMMA_RTOL
     assert np.all(np.abs(out[ll_key][same] - ref_ll[same]) <= LL_RTOL * np.abs(ref_ll[same]) + LL_ATOL)
@@ -107,7 +111,7 @@ def test_ap_train_k10_matches_reference_goldens(capi, ap_train):
 def test_ap_heldout_k10_matches_reference_goldens(capi, ap_test):
     g = ap_test
     out = run(capi, g["alpha"], g["eta"], g["doc_ptr"], g["term_id"], g["term_ct"], heldout=True)
-    check_against(out, g["gamma"], g["words_ll"], g["iters"], ll_key="doc_words_ll", min_same=0.99)
+    check_against(out, g["gamma"], g["words_ll"], g["iters"], ll_key="doc_words_ll")
     assert abs(out["words_log_likelihood"] - float(g["corpus_words_ll"])) < 1e-9 * abs(float(g["corpus_words_ll"]))
 
 
@@ -133,7 +137,7 @@ def test_logspace_safety_net_kernel_matches(capi, ap_train, ap_test):
     h = ap_test
     held = run(capi, h["alpha"], h["eta"], h["doc_ptr"], h["term_id"], h["term_ct"], heldout=True,
                options=[("force_logspace", 1)])
-    check_against(held, h["gamma"], h["words_ll"], h["iters"], ll_key="doc_words_ll", min_same=0.99)
+    check_against(held, h["gamma"], h["words_ll"], h["iters"], ll_key="doc_words_ll")
 
 
 def test_collapsed_alpha_triggers_safety_net(capi):
@@ -189,13 +193,13 @@ def test_random_corpora_against_c_oracle(capi, K, V, D, mean_len):
     alpha = rng.uniform(0.05, 1.5, K)
     ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
     out = run(capi, alpha, eta, ptr, ids, cts)
-    check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
+    check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"])
     assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
     assert abs(out["sstats"].sum() - cts.sum()) < 1e-7 * cts.sum()
     held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
     held = run(capi, alpha, eta, ptr, ids, cts, heldout=True)
     check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"],
-                  ll_key="doc_words_ll", min_same=0.95)
+                  ll_key="doc_words_ll")
 
 
 @pytest.mark.parametrize("K,V,mean_len", [(10, 300, 20), (16, 300, 150), (17, 400, 90), (32, 500, 260),
@@ -215,13 +219,13 @@ def test_register_resident_slab_kernels(capi, K, V, mean_len):
     held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
     for variant in (4, 6, 7, 8, 9, 10):          # slab, quilt (register tiles), streaming, hybrid, wide tiered, quad
         out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
-        check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
+        check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"])
         assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
-        assert np.mean(out["iters"] == gen["iters"]) >= 0.95
+        assert np.array_equal(out["iters"], gen["iters"])
         assert rel_err(out["gamma"], gen["gamma"]) < 1e-9
         held = run(capi, alpha, eta, ptr, ids, cts, heldout=True, options=[("force_variant", variant)])
         check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"],
-                      ll_key="doc_words_ll", min_same=0.95)
+                      ll_key="doc_words_ll")
         # bitwise reproducible: fixed summation order (and an order-independent convergence sum)
         again = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
         assert np.array_equal(out["gamma"], again["gamma"]) and np.array_equal(out["sstats"], again["sstats"])
@@ -243,13 +247,13 @@ def test_wide_table_kernels_agree(capi, K, V, mean_len):
     held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
     for variant in (10, 9, 8, 7):
         out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
-        check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
+        check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"])
         assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
-        assert np.mean(out["iters"] == gen["iters"]) >= 0.95
+        assert np.array_equal(out["iters"], gen["iters"])
         assert rel_err(out["gamma"], gen["gamma"]) < 1e-9
         held = run(capi, alpha, eta, ptr, ids, cts, heldout=True, options=[("force_variant", variant)])
         check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"],
-                      ll_key="doc_words_ll", min_same=0.95)
+                      ll_key="doc_words_ll")
         again = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
         assert np.array_equal(out["gamma"], again["gamma"]) and np.array_equal(out["sstats"], again["sstats"])
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
@@ -272,12 +276,12 @@ def test_fused_streaming_kernel_agrees(capi, K, V, mean_len):
     held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
     for variant in (11, 7):
         out = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
-        check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"], min_same=0.95)
+        check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"])
         assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
-        assert np.mean(out["iters"] == gen["iters"]) >= 0.95
+        assert np.array_equal(out["iters"], gen["iters"])
         held = run(capi, alpha, eta, ptr, ids, cts, heldout=True, options=[("force_variant", variant)])
         check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"],
-                      ll_key="doc_words_ll", min_same=0.95)
+                      ll_key="doc_words_ll")
         again = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", variant)])
         assert np.array_equal(out["gamma"], again["gamma"]) and np.array_equal(out["sstats"], again["sstats"])
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
@@ -518,3 +522,18 @@ def test_error_reporting(capi):
     assert np.isfinite(ll) and abs(big.get_sstats().sum() - 4000) < 1e-8
     ok.close()
     big.close()
+
+
+def test_randomised_parity_sweep(capi):
+    """tools/fuzz_parity.py for 30 s: K from 1 to 512, documents of 1 to ~600 terms, alpha from 0.005 to 1.5, three
+    thresholds, random settings of the statistics gather - every document stops on the C oracle's inner iteration
+    (the tolerances on log-likelihood, gamma, statistics and the fast path are asserted inside the sweep)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    got = mod.sweep(30.0, seed=3, verbose=False)
+    assert got["cases"] >= 20 and got["documents"] >= 200, got
+    assert got["flips"] == 0, got

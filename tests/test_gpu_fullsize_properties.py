@@ -111,9 +111,12 @@ def test_oracle_spot_check_on_full_size_run(cfg3):
         assert ("quad", 321003) in kernels and ("quad", 321002) in kernels, kernels   # the bulk: all words on chip
     from conftest import csr_slice
     ptr, tid, tct = csr_slice(c["ptr"], c["ids"], c["cts"], docs)
-    ref = c_oracle.e_step(c["alpha"], c["eta"], ptr, tid, tct)
-    same = ref["iters"] == c["iters"][docs]
-    assert same.mean() >= 0.9
-    assert rel_err(c["gamma"][docs][same], ref["gamma"][same]) < 1e-9
-    assert rel_err(c["doc_ll"][docs][same], ref["doc_ll"][same]) < 1e-9
-    assert rel_err(c["doc_ll"][docs], ref["doc_ll"]) < 1e-5                 # the stated bar, all sampled documents
+    # the sampled documents against BOTH restatements: the numpy/scipy one executes the reference's own operations
+    # in the reference's order (bit-pinned to its goldens, tests/test_oracle_golden.py), the C one is the checker of
+    # the random-shape tests; every sampled document must stop on the reference's inner iteration
+    from oracle import vb_numpy
+    for name, ref in (("numpy", vb_numpy.e_step(c["alpha"], c["eta"], ptr, tid, tct)),
+                      ("c", c_oracle.e_step(c["alpha"], c["eta"], ptr, tid, tct))):
+        assert np.array_equal(ref["iters"], c["iters"][docs]), (name, ref["iters"], c["iters"][docs])
+        assert rel_err(c["gamma"][docs], ref["gamma"]) < 1e-9, name
+        assert rel_err(c["doc_ll"][docs], ref["doc_ll"]) < 1e-9, name      # (the stated bar is 1e-5)
