@@ -26,6 +26,7 @@
 #include "estep_quad.h"
 #include "doc_terms.h"
 #include "estep_qfuse.h"
+#include "estep_qfusek.h"
 #include "estep_qstream.h"
 #include "estep_qhybrid.h"
 #include "estep_qwide.h"
@@ -52,7 +53,10 @@ enum Variant : int {
     kQhybrid = 8,       // tile split over registers / LDS / streamed remainder (estep_qhybrid.h)
     kQwide = 9,         // the same three tiers on a 2 x 32 lane grid with prefetched tail rows (estep_qwide.h)
     kQuad = 10,         // 16 word groups / document, tile in registers + LDS rows (estep_quad.h)
-    kQfuse = 11         // table stride 512: rows streamed ONCE per iteration, normaliser and topic sums fused (estep_qfuse.h)
+    kQfuse = 11,        // table stride 512: rows streamed ONCE per iteration, normaliser and topic sums fused (estep_qfuse.h)
+    kGenericHuge = 12,  // a document too long even for its per-term scalars in LDS: those in global memory too (estep_generic.h MODE 2)
+    kQfusek = 13,       // table stride 640 .. 1024: every row streamed once per iteration, fused (estep_qfusek.h)
+    kVariantLast = kQfusek
 };
 
 struct Launch {
@@ -122,7 +126,6 @@ struct pylda_ctx {
     int quilt12 = 0;
     int gather_rows = 2;            // 0: 64-topic chunks; 1: whole rows (ldk 64 / 128 / 256); 2: + postings in bulk (ldk 128 / 256)
     int gather_blocks = -1;         // document blocks of the gather: -1 automatic, 0 / 1 off, n forced (multiple of 8)
-    int quad_tune = 0;              // A/B: start delay / priority of the second co-resident workgroup (estep_quad.h)
     int lds_pad = 0;                // A/B: extra dynamic LDS per quad workgroup (forces one workgroup per CU)
     int quad = 1;                   // register + LDS tile kernel (estep_quad.h) for table strides 128 / 256, N <= 208
     int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
@@ -162,6 +165,7 @@ struct pylda_corpus {
     bool last_doc_values = true;
     double* d_tfinal = nullptr;    // D x ldk
     double* d_rfinal = nullptr;    // nnz
+    double* d_term_scratch = nullptr;   // nnz, only when a launch class needs it (kGenericHuge)
     // postings (CSC) of the corpus for the sufficient-statistics gather pass
     bool have_postings = false;
     int32_t* d_post_doc = nullptr; // nnz
@@ -309,6 +313,11 @@ int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
         *lds_bytes = 0;
         return kQfuse;
     }
+    if ((ctx->force_variant < 0 || ctx->force_variant == kQfusek) && ctx->ldk > 512 && ctx->ldk <= 1024 && ctx->ldk % 128 == 0 &&
+        n <= 8 * kQfMaxSlots && ctx->lds_limit >= 160 * 1024) {
+        *lds_bytes = 0;
+        return kQfusek;
+    }
     if ((ctx->force_variant < 0 || ctx->force_variant == kQuilt) && quilt_geom_for(ctx, n).W > 0) {
         *lds_bytes = 0;
         return kQuilt;
@@ -336,6 +345,7 @@ generic:
     const size_t l512 = generic_lds_layout(K, n, stride, 512, false).total;
     int v;
     if (ctx->force_variant >= 0 && ctx->force_variant < kSlab) v = ctx->force_variant;
+    else if (ctx->force_variant == kGenericHuge) v = kGenericGlobal;
     else if (l64 <= 20 * 1024) v = kGeneric64;
     else if (l256 <= 64 * 1024) v = kGeneric256;
     else if (l512 <= ctx->lds_limit) v = kGeneric512;
@@ -343,10 +353,15 @@ generic:
     // a forced LDS variant that does not fit degrades to the global-tile kernel
     const size_t need = v == kGeneric64 ? l64 : v == kGeneric256 ? l256 : l512;
     if (v != kGenericGlobal && need > ctx->lds_limit) v = kGenericGlobal;
+    // ... and a document whose per-term scalars (28 bytes per distinct term) do not fit either keeps those in
+    // global memory as well: any length runs
+    if (v == kGenericGlobal && (ctx->force_variant == kGenericHuge || generic_lds_layout(K, n, stride, 256, true).total > ctx->lds_limit))
+        v = kGenericHuge;
     switch (v) {
     case kGeneric64: *lds_bytes = l64; break;
     case kGeneric256: *lds_bytes = l256; break;
     case kGeneric512: *lds_bytes = l512; break;
+    case kGenericHuge: *lds_bytes = generic_lds_layout(K, 0, stride, 256, true).total; break;
     default: *lds_bytes = generic_lds_layout(K, n, stride, 256, true).total; break;
     }
     return v;
@@ -400,10 +415,10 @@ void build_plan(pylda_corpus* c)
     }
 }
 
-template <int NT, bool TG>
+template <int NT, int MODE>
 int launch_generic(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
-    auto kern = estep_generic_kernel<NT, TG>;
+    auto kern = estep_generic_kernel<NT, MODE>;
     if (L.lds_bytes > 64 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -513,6 +528,28 @@ int launch_qfuse_np(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 int launch_qfuse(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
     return ctx->ldk == 512 ? launch_qfuse_np<4, 6, 2>(ctx, p, L) : launch_qfuse_np<3, 8, 3>(ctx, p, L);
+}
+
+template <int NP>
+int launch_qfusek_np(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    auto kern = estep_qfusek_kernel<NP>;
+    const size_t lds = QfusekLds<NP>::total;
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(512), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+int launch_qfusek(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+{
+    switch (ctx->ldk / 128) {
+    case 5: return launch_qfusek_np<5>(ctx, p, L);
+    case 6: return launch_qfusek_np<6>(ctx, p, L);
+    case 7: return launch_qfusek_np<7>(ctx, p, L);
+    case 8: return launch_qfusek_np<8>(ctx, p, L);
+    }
+    return fail(ctx, PYLDA_ERR_STATE, "no fused streaming kernel for table stride %d", ctx->ldk);
 }
 
 template <int KRL>
@@ -850,9 +887,9 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     ctx->device = device;
     ctx->K = K;
     ctx->V = V;
-    // table stride: K rounded up to 16 / 32 / a multiple of 64, above 256 to a multiple of 128 (the fused
-    // streaming kernel's rows are 64 lanes x 16-byte pieces)
-    ctx->ldk = K <= 16 ? 16 : K <= 32 ? 32 : K <= 256 ? (K + 63) / 64 * 64 : K <= 512 ? (K + 127) / 128 * 128 : (K + 63) / 64 * 64;
+    // table stride: K rounded up to 16 / 32 / a multiple of 64, from 257 to 1024 to a multiple of 128 (the fused
+    // streaming kernels' rows are 64 lanes x 16-byte pieces)
+    ctx->ldk = K <= 16 ? 16 : K <= 32 ? 32 : K <= 256 ? (K + 63) / 64 * 64 : K <= 1024 ? (K + 127) / 128 * 128 : (K + 63) / 64 * 64;
     auto bail = [&](int code) {
         g_create_error = ctx->err;
         pylda_destroy(ctx);
@@ -972,7 +1009,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kQfuse || value == kRetired5)
+        if (value < -1 || value > kVariantLast || value == kRetired5)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld is not a kernel variant", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
@@ -984,8 +1021,6 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     } else if (!strcmp(name, "quilt_odd")) {
         ctx->quilt_odd = value != 0;
         ctx->plan_epoch += 1;
-    } else if (!strcmp(name, "quad_tune")) {
-        ctx->quad_tune = (int)value;
     } else if (!strcmp(name, "lds_pad")) {
         ctx->lds_pad = (int)value;
     } else if (!strcmp(name, "quad")) {
@@ -1018,14 +1053,13 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
     }
     const int64_t nnz = doc_ptr[D];
     {
-        // the most general kernel keeps per-term scalars of one document in LDS
-        const size_t need = generic_lds_layout(ctx->K, (int)std::min<int64_t>(max_terms, 1 << 24),
-                                               tile_stride_for(ctx->K), 256, true).total;
-        if (max_terms > (1 << 24) || need > ctx->lds_limit)
-            return fail(ctx, PYLDA_ERR_INVALID,
-                        "corpus_create: a document has %lld distinct terms; at K=%d the kernels support up to about %lld",
-                        (long long)max_terms, ctx->K,
-                        (long long)((ctx->lds_limit - generic_lds_layout(ctx->K, 0, tile_stride_for(ctx->K), 256, true).total) / 28));
+        // the most general kernel (estep_generic.h MODE 2) needs only K-sized arrays in LDS: any document length
+        const size_t need = generic_lds_layout(ctx->K, 0, tile_stride_for(ctx->K), 256, true).total;
+        if (need > ctx->lds_limit || logspace_lds_bytes(ctx->K) > ctx->lds_limit)
+            return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: K=%d needs %zu bytes of LDS per document (limit %zu)", ctx->K,
+                        std::max(need, logspace_lds_bytes(ctx->K)), ctx->lds_limit);
+        if (max_terms > INT32_MAX)
+            return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: a document has %lld distinct terms", (long long)max_terms);
     }
     if (nnz > INT32_MAX)
         return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: %lld distinct (doc, term) pairs exceed 2^31-1 per device; shard the corpus", (long long)nnz);
@@ -1109,7 +1143,7 @@ void pylda_corpus_destroy(pylda_corpus* c)
     dev_free(c->d_doc_ptr); dev_free(c->d_term_id); dev_free(c->d_term_ct); dev_free(c->d_order);
     dev_free(c->d_gamma); dev_free(c->d_doc_ll); dev_free(c->d_doc_wll); dev_free(c->d_iters);
     dev_free(c->d_status); dev_free(c->d_flag_list); dev_free(c->d_flag_count); dev_free(c->d_scalars); dev_free(c->d_entropy_partial);
-    dev_free(c->d_tfinal); dev_free(c->d_rfinal); dev_free(c->d_post_doc); dev_free(c->d_post_pos);
+    dev_free(c->d_tfinal); dev_free(c->d_rfinal); dev_free(c->d_term_scratch); dev_free(c->d_post_doc); dev_free(c->d_post_pos);
     dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial); dev_free(c->d_exec_order);
     delete c;
 }
@@ -1218,13 +1252,21 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     p.tfinal = c->d_tfinal;
     p.rfinal = c->d_rfinal;
     p.status = c->d_status;
-    p.tune = ctx->quad_tune;
+    p.term_scratch = c->d_term_scratch;
 
     {
         const double span = tol * K;
         ctx->exact_stop = !(span >= 3.725290298461914e-09 /* 2^-28 */ && span < 1024.0);
     }
     if (c->plan_epoch != ctx->plan_epoch || c->plan_exact != ctx->exact_stop) build_plan(c);
+    if (!c->d_term_scratch)
+        for (const Launch& L : c->plan)
+            if (L.variant == kGenericHuge) {
+                rc = dev_alloc(ctx, &c->d_term_scratch, (size_t)c->nnz);
+                if (rc != PYLDA_OK) return rc;
+                p.term_scratch = c->d_term_scratch;
+                break;
+            }
     auto open_bracket = [&](int slot, hipStream_t st) -> int {      // index into pending_events, or -1
         if (!ctx->profiling) return -1;
         pylda_ctx::Bracket br{take_event(ctx), take_event(ctx), slot};
@@ -1268,9 +1310,10 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             p.tile_stride = L.tile_stride;
             const int class_bracket = open_bracket(slot, ctx->stream);
             switch (L.variant) {
-            case kGeneric64: rc = launch_generic<64, false>(ctx, p, L); break;
-            case kGeneric256: rc = launch_generic<256, false>(ctx, p, L); break;
-            case kGeneric512: rc = launch_generic<512, false>(ctx, p, L); break;
+            case kGeneric64: rc = launch_generic<64, 0>(ctx, p, L); break;
+            case kGeneric256: rc = launch_generic<256, 0>(ctx, p, L); break;
+            case kGeneric512: rc = launch_generic<512, 0>(ctx, p, L); break;
+            case kGenericHuge: rc = launch_generic<256, 2>(ctx, p, L); break;
             case kSlab: rc = launch_slab_any(ctx, p, L); break;
             case kQuilt: rc = launch_quilt_any(ctx, p, L); break;
             case kQstream: rc = launch_qstream_any(ctx, p, L); break;
@@ -1278,7 +1321,8 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kQwide: rc = launch_qwide_any(ctx, p, L); break;
             case kQuad: rc = launch_quad_any(ctx, p, L); break;
             case kQfuse: rc = launch_qfuse(ctx, p, L); break;
-            default: rc = launch_generic<256, true>(ctx, p, L); break;
+            case kQfusek: rc = launch_qfusek(ctx, p, L); break;
+            default: rc = launch_generic<256, 1>(ctx, p, L); break;
             }
             close_bracket(class_bracket, ctx->stream);
             if (rc != PYLDA_OK) {
@@ -1313,6 +1357,9 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
                            ctx->stream, c->d_status, c->D, c->d_flag_list, c->d_flag_count);
         p.order = nullptr;
         const unsigned grid = (unsigned)std::min<int64_t>(c->D, 4 * (int64_t)ctx->num_cu);
+        if (logspace_lds_bytes(K) > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(estep_logspace_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)logspace_lds_bytes(K)));
         hipLaunchKernelGGL(estep_logspace_kernel, dim3(grid), dim3(256), logspace_lds_bytes(K),
                            ctx->stream, p, ctx->d_elog, ctx->d_sstats, c->d_flag_list, c->d_flag_count);
     }

@@ -40,7 +40,7 @@ struct EstepParams {
     int32_t* status;          // D out: 0 ok, 1 = linear-space normaliser under/overflowed
     int n_cap;                // max distinct terms of any document in this launch
     int tile_stride;          // LDS row stride in doubles (odd)
-    int tune;                 // experiments (option quad_tune): see estep_quad.h
+    double* term_scratch;     // nnz scratch doubles, only for documents too long for the LDS (estep_generic.h MODE 2)
 };
 
 // Sum over the 64 lanes, result in every lane, without the LDS crossbar (ds_bpermute costs an LDS

@@ -14,10 +14,14 @@
 // gamma, :177-188) for the entropy term (:199), the held-out word
 // likelihood (:204) and the sufficient statistics (:207).
 //
-// TILE_GLOBAL=false: the N_d x K tile of B is staged once in LDS (odd row
-// stride => conflict-free ds_read_b64 in both passes) and every inner
-// iteration runs out of LDS.  TILE_GLOBAL=true: the tile does not fit the
-// 160 KiB LDS; rows are re-read from the table (L2 / Infinity Cache).
+// MODE 0: the N_d x K tile of B is staged once in LDS (odd row stride =>
+// conflict-free ds_read_b64 in both passes) and every inner iteration runs
+// out of LDS.  MODE 1: the tile does not fit the 160 KiB LDS; rows are
+// re-read from the table (L2 / Infinity Cache).  MODE 2: neither do the
+// per-term scalars (28 bytes per distinct term: above ~5,000 terms) - r_n
+// lives in the corpus' rfinal array, the normalisers in a per-corpus scratch
+// array, ids and counts are read where they lie: a document of ANY length
+// runs (the reference accepts any, variational_bayes.py:98-130), slowly.
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
@@ -53,9 +57,11 @@ __host__ __device__ inline GenericLds generic_lds_layout(int K, int n_cap, int t
     return L;
 }
 
-template <int NT, bool TILE_GLOBAL>
+template <int NT, int MODE>
 __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
 {
+    constexpr bool TILE_GLOBAL = MODE >= 1;
+    constexpr bool TERMS_GLOBAL = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = p.K;
     const int tid = threadIdx.x;
@@ -64,15 +70,19 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
     const int N = (int)(p.doc_ptr[doc + 1] - lo);
     const int stride = TILE_GLOBAL ? p.ldk : p.tile_stride;
 
-    const GenericLds L = generic_lds_layout(K, p.n_cap, p.tile_stride, NT, TILE_GLOBAL);
+    const GenericLds L = generic_lds_layout(K, TERMS_GLOBAL ? 0 : p.n_cap, p.tile_stride, NT, TILE_GLOBAL);
     double* tile = reinterpret_cast<double*>(smem + L.tile);
     double* t = reinterpret_cast<double*>(smem + L.t);
     double* lt = reinterpret_cast<double*>(smem + L.lt);
     double* gam = reinterpret_cast<double*>(smem + L.gam);
-    double* r = reinterpret_cast<double*>(smem + L.r);
-    double* lognrm = reinterpret_cast<double*>(smem + L.lognrm);
+    // per-term scalars: LDS, or (MODE 2) global memory - written and read by this workgroup only, between
+    // __syncthreads() (workgroup-scope release / acquire; one CU, one L1)
+    double* r = TERMS_GLOBAL ? p.rfinal + lo : reinterpret_cast<double*>(smem + L.r);
+    double* lognrm = TERMS_GLOBAL ? p.term_scratch + lo : reinterpret_cast<double*>(smem + L.lognrm);
     double* cts = reinterpret_cast<double*>(smem + L.cts);
     int* ids = reinterpret_cast<int*>(smem + L.ids);
+    auto id_of = [&](int n) -> int { if constexpr (TERMS_GLOBAL) return p.term_id[lo + n]; else return ids[n]; };
+    auto ct_of = [&](int n) -> double { if constexpr (TERMS_GLOBAL) return (double)p.term_ct[lo + n]; else return cts[n]; };
     double* red = reinterpret_cast<double*>(smem + L.red);
     double* scratch = reinterpret_cast<double*>(smem + L.scratch);
 
@@ -90,8 +100,10 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
     for (int n = tid; n < N; n += NT) {
         const int id = p.term_id[lo + n];
         const double c = (double)p.term_ct[lo + n];
-        ids[n] = id;
-        cts[n] = c;
+        if constexpr (!TERMS_GLOBAL) {
+            ids[n] = id;
+            cts[n] = c;
+        }
         local += c;
     }
     const double total = block_sum<NT>(local, scratch);
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
     __syncthreads();
 
     auto row = [&](int n) -> const double* {
-        if constexpr (TILE_GLOBAL) return p.expElog + (size_t)ids[n] * p.ldk;
+        if constexpr (TILE_GLOBAL) return p.expElog + (size_t)id_of(n) * p.ldk;
         else return tile + (size_t)n * stride;
     };
 
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
             if (k < K) a0 = fma(b[k], t[k], a0);
             const double nrm = a0 + a1;
             if (!(nrm > 1e-280 && nrm < 1e300)) bad = 1;
-            r[n] = cts[n] / nrm;
+            r[n] = ct_of(n) / nrm;
             lognrm[n] = nrm;          // the log is taken once, after the loop
         }
         __syncthreads();
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
     for (int n = g; n < N; n += G) {
         const double* b = row(n);
         const double rn = r[n], ln = lognrm[n];
-        const double sh = p.heldout ? p.shift[ids[n]] : 0.0;
+        const double sh = p.heldout ? p.shift[id_of(n)] : 0.0;
         for (int kk = kl; kk < K; kk += KL) {
             const double bv = b[kk];
             const double pc = bv * t[kk] * rn;             // phi * count
@@ -211,7 +223,8 @@ __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)
     // factors t (per document) and r (per term) are handed to the gather pass
     // (sstats_kernels.h), which sums them word by word without atomics.
     if (!p.heldout) {
-        for (int n = tid; n < N; n += NT) p.rfinal[lo + n] = r[n];
+        if constexpr (!TERMS_GLOBAL)
+            for (int n = tid; n < N; n += NT) p.rfinal[lo + n] = r[n];
         for (int k = tid; k < p.ldk; k += NT) p.tfinal[(size_t)doc * p.ldk + k] = k < K ? t[k] : 0.0;
     }
 

@@ -141,20 +141,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     if constexpr (TL == 32) {
         if (wave < 4) __builtin_amdgcn_s_setprio(2);
     }
-    if (p.tune) {
-        // experiment: the workgroup in the SIMDs' second wave slot starts late (units of 64 ticks) and / or runs
-        // at another priority, so that the two co-resident documents are out of phase / the older one is not preferred
-        unsigned hw_id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        if (hw_id & 1) {
-            const int prio = (p.tune >> 16) & 3;
-            if (prio == 1) __builtin_amdgcn_s_setprio(1);
-            else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-            else if (prio == 3) __builtin_amdgcn_s_setprio(3);
-            const long long until = __builtin_amdgcn_s_memtime() + (long long)(p.tune & 0xffff) * 64;
-            while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     const int g = lane / TL, c = lane % TL;
     const int cl = lane & 15;               // position inside the 16-lane row
     const int half = (lane >> 4) & (TL / 16 - 1);   // row of a 32-lane group

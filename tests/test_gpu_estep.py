@@ -537,3 +537,91 @@ def test_randomised_parity_sweep(capi):
     got = mod.sweep(30.0, seed=3, verbose=False)
     assert got["cases"] >= 20 and got["documents"] >= 200, got
     assert got["flips"] == 0, got
+
+
+def _random_corpus(rng, V, lengths):
+    ptr, ids, cts = [0], [], []
+    for n in lengths:
+        ids.append(np.sort(rng.choice(V, size=n, replace=False)).astype(np.int32))
+        cts.append(rng.integers(1, 5, size=n).astype(np.int32))
+        ptr.append(ptr[-1] + n)
+    return np.array(ptr, np.int64), np.concatenate(ids), np.concatenate(cts)
+
+
+def test_a_document_of_twenty_thousand_terms_at_k700(capi):
+    """The reference accepts any document length and any K (variational_bayes.py:98-130, :132).  One document
+    of 20,000 distinct terms - 560 KB of per-term scalars alone, more than the LDS holds - beside ordinary ones,
+    K = 700: training and held-out mode against the C oracle."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(5)
+    K, V = 700, 30000
+    ptr, ids, cts = _random_corpus(rng, V, [20000, 5, 130, 6100, 1])
+    eta = rng.gamma(100.0, 0.01, (K, V))
+    alpha = np.full(K, 0.05)
+    ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
+    ctx = capi.Context(K, V)
+    corpus = ctx.corpus(ptr, ids, cts)
+    kernels = {c["kernel"] for c in corpus.plan()}
+    assert "generic_huge" in kernels, kernels
+    out = ctx.estep_host(corpus, alpha, eta)
+    check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"])
+    assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+    assert abs(out["sstats"].sum() - cts.sum()) < 1e-6
+    held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
+    held = ctx.estep_host(corpus, alpha, eta, heldout=True)
+    check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"], ll_key="doc_words_ll")
+    # the training fast path (what learning() runs) gives the same corpus likelihood
+    ctx.set_option("doc_values", 0)
+    ctx.estep(corpus)
+    assert abs(ctx.estep_results(corpus)[0] - out["document_log_likelihood"]) < 1e-10 * abs(out["document_log_likelihood"])
+    corpus.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("K,V,lengths", [(700, 1500, (230, 1, 9, 64, 410, 1024, 1025, 17, 2)),
+                                         (1000, 2000, (300, 8, 16, 7, 1000, 129)),
+                                         (520, 1200, (5, 250, 250, 33, 900)),
+                                         (800, 1300, (180, 2, 640, 15, 16)),
+                                         (1024, 1100, (40, 1024, 3))])
+def test_fused_streaming_kernel_above_512_topics(capi, K, V, lengths):
+    """512 < K <= 1024 (table stride 640 .. 1024): every row streamed once per inner iteration, two buffers in flight
+    (estep_qfusek.h) - against the C oracle and the generic kernel, training and held-out, early stops, bitwise
+    repeatable; documents of 1 term, of exactly 8 slots x 128 (the kernel's capacity) and one beyond it (generic)."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(K + V)
+    ptr, ids, cts = _random_corpus(rng, V, lengths)
+    eta = rng.gamma(100.0, 0.01, (K, V))
+    eta[:, rng.choice(V, V // 4, replace=False)] = 1.0 / V
+    alpha = rng.uniform(0.05, 1.5, K)
+    ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
+    ctx = capi.Context(K, V)
+    corpus = ctx.corpus(ptr, ids, cts)
+    kernels = {c["kernel"] for c in corpus.plan()}
+    assert "qfusek" in kernels and (max(lengths) <= 1024 or kernels & {"generic_global", "generic512", "generic_huge"}), kernels
+    corpus.close()
+    ctx.close()
+    gen = run(capi, alpha, eta, ptr, ids, cts, options=[("force_variant", 3)])
+    out = run(capi, alpha, eta, ptr, ids, cts)
+    check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"])
+    assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+    assert np.array_equal(out["iters"], gen["iters"]) and rel_err(out["gamma"], gen["gamma"]) < 1e-9
+    held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
+    held = run(capi, alpha, eta, ptr, ids, cts, heldout=True)
+    check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"], ll_key="doc_words_ll")
+    again = run(capi, alpha, eta, ptr, ids, cts)
+    assert np.array_equal(out["gamma"], again["gamma"]) and np.array_equal(out["sstats"], again["sstats"])
+    assert np.array_equal(out["doc_ll"], again["doc_ll"])
+    for mi, tol in [(1, 1e-6), (3, 1e-6), (50, 1e-2)]:
+        ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
+        out = run(capi, alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
+        assert np.array_equal(out["iters"], ref["iters"]), (mi, tol)
+        assert rel_err(out["gamma"], ref["gamma"]) < 1e-9
+    # the training fast path (doc_terms pass) agrees with the complete per-document values
+    ctx = capi.Context(K, V)
+    corpus = ctx.corpus(ptr, ids, cts)
+    full = ctx.estep_host(corpus, alpha, eta)
+    ctx.set_option("doc_values", 0)
+    ctx.estep(corpus)
+    assert abs(ctx.estep_results(corpus)[0] - full["document_log_likelihood"]) < 1e-10 * abs(full["document_log_likelihood"])
+    corpus.close()
+    ctx.close()
