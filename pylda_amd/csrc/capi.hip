@@ -126,6 +126,7 @@ struct pylda_ctx {
     int quilt12 = 0;
     int gather_rows = 2;            // 0: 64-topic chunks; 1: whole rows (ldk 64 / 128 / 256); 2: + postings in bulk (ldk 128 / 256)
     int gather_blocks = -1;         // document blocks of the gather: -1 automatic, 0 / 1 off, n forced (multiple of 8)
+    int wide_postings = 0;          // test hook: 64-bit CSR positions in the postings whatever nnz (automatic from 2^31 pairs)
     int lds_pad = 0;                // A/B: extra dynamic LDS per quad workgroup (forces one workgroup per CU)
     int quad = 1;                   // register + LDS tile kernel (estep_quad.h) for table strides 128 / 256, N <= 208
     int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
@@ -169,7 +170,8 @@ struct pylda_corpus {
     // postings (CSC) of the corpus for the sufficient-statistics gather pass
     bool have_postings = false;
     int32_t* d_post_doc = nullptr; // nnz
-    int32_t* d_post_pos = nullptr; // nnz: position in CSR order
+    void* d_post_pos = nullptr;    // nnz: position in CSR order (int32, or int64 when wide_pos)
+    bool wide_pos = false;         // nnz >= 2^31 (or option wide_postings): 64-bit CSR positions in the postings
     int64_t* d_seg_begin = nullptr;
     int64_t* d_seg_end = nullptr;
     int32_t* d_exec_order = nullptr;   // document-blocked gather: segment of every (workgroup, wavefront) slot, or -1
@@ -658,13 +660,37 @@ int build_postings(pylda_corpus* c)
     const int64_t nnz = c->nnz;
     int rc = PYLDA_OK;
     auto A = [&](int r) { if (rc == PYLDA_OK) rc = r; };
+    // every exit below that is not the last line leaves the corpus without postings AND without their arrays: a
+    // retry (the next training E-step) starts from scratch instead of leaking nnz * 8 bytes or more per attempt
+    struct Undo {
+        pylda_corpus* c;
+        bool keep = false;
+        ~Undo()
+        {
+            if (keep) return;
+            dev_free(c->d_post_doc);
+            if (c->d_post_pos) (void)hipFree(c->d_post_pos);
+            c->d_post_pos = nullptr;
+            dev_free(c->d_exec_order); dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial);
+            c->nseg = 0;
+            c->exec_slots = 0;
+        }
+    } undo{c};
+    c->wide_pos = ctx->wide_postings || nnz > INT32_MAX;
     A(dev_alloc(ctx, &c->d_post_doc, (size_t)nnz));
-    A(dev_alloc(ctx, &c->d_post_pos, (size_t)nnz));
+    if (rc == PYLDA_OK) {
+        const size_t bytes = (size_t)std::max<int64_t>(nnz, 1) * (c->wide_pos ? sizeof(int64_t) : sizeof(int32_t));
+        const hipError_t ea = hipMalloc(&c->d_post_pos, bytes);
+        if (ea != hipSuccess) {
+            c->d_post_pos = nullptr;
+            rc = fail(ctx, ea == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, "postings: hipMalloc: %s", hipGetErrorString(ea));
+        }
+    }
     if (rc != PYLDA_OK) return rc;
     std::vector<int64_t> col_ptr((size_t)V + 1, 0);
     const char* what = "";
     const hipError_t e = build_postings_device(ctx->stream, V, c->D, nnz, c->d_doc_ptr, c->d_term_id, c->d_post_doc,
-                                               c->d_post_pos, col_ptr.data(), &what);
+                                               c->d_post_pos, c->wide_pos, col_ptr.data(), &what);
     if (e != hipSuccess)
         return fail(ctx, e == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     std::vector<int64_t> seg_begin, seg_end, word_seg_ptr((size_t)V + 1, 0);
@@ -769,46 +795,47 @@ int build_postings(pylda_corpus* c)
     H2D(c->d_word_seg_ptr, word_seg_ptr.data(), ((size_t)V + 1) * sizeof(int64_t));
     if (rc != PYLDA_OK) return rc;
     c->have_postings = true;
+    undo.keep = true;
     return PYLDA_OK;
 }
 
 #ifndef PYLDA_GATHER_U
 #define PYLDA_GATHER_U 4        // rows in flight per wavefront (cfg 3, 24 blocks: 4 -> 1.62 ms, 8 -> 1.71, 16 -> 2.3: occupancy)
 #endif
+template <typename P>
+void launch_gather(pylda_ctx* ctx, pylda_corpus* c)
+{
+    const int ldk = ctx->ldk;
+    const P* pos = static_cast<const P*>(c->d_post_pos);
+    const dim3 grid((unsigned)((c->nseg + 3) / 4), (unsigned)((ldk + 63) / 64));
+    const dim3 g1((unsigned)(((c->d_exec_order ? c->exec_slots : c->nseg) + 3) / 4));
+#define GATHER_ARGS c->d_seg_begin, c->d_seg_end, c->nseg, c->d_post_doc, pos, c->d_tfinal, c->d_rfinal
+    if (ldk == 16)
+        hipLaunchKernelGGL((sstats_gather_kernel<16, P>), grid, dim3(256), 0, ctx->stream, GATHER_ARGS, ldk, c->d_partial);
+    else if (ldk == 32)
+        hipLaunchKernelGGL((sstats_gather_kernel<32, P>), grid, dim3(256), 0, ctx->stream, GATHER_ARGS, ldk, c->d_partial);
+    else if (ctx->gather_rows && (ldk == 64 || ldk == 128 || ldk == 256)) {
+        if (ldk == 128 && ctx->gather_rows == 2)
+            hipLaunchKernelGGL((sstats_gather_bulk_kernel<2, PYLDA_GATHER_U, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, c->d_exec_order);
+        else if (ldk == 256 && ctx->gather_rows == 2)
+            hipLaunchKernelGGL((sstats_gather_bulk_kernel<4, PYLDA_GATHER_U, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, c->d_exec_order);
+        else if (ldk == 64)
+            hipLaunchKernelGGL((sstats_gather_rows_kernel<1, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, c->d_exec_order);
+        else if (ldk == 128)
+            hipLaunchKernelGGL((sstats_gather_rows_kernel<2, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, c->d_exec_order);
+        else
+            hipLaunchKernelGGL((sstats_gather_rows_kernel<4, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, c->d_exec_order);
+    } else
+        hipLaunchKernelGGL((sstats_gather_kernel<64, P>), grid, dim3(256), 0, ctx->stream, GATHER_ARGS, ldk, c->d_partial);
+#undef GATHER_ARGS
+}
+
 int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
 {
     const int ldk = ctx->ldk;
     if (c->nseg > 0) {
-        const dim3 grid((unsigned)((c->nseg + 3) / 4), (unsigned)((ldk + 63) / 64));
-        if (ldk == 16)
-            hipLaunchKernelGGL(sstats_gather_kernel<16>, grid, dim3(256), 0, ctx->stream, c->d_seg_begin,
-                               c->d_seg_end, c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal,
-                               c->d_rfinal, ldk, c->d_partial);
-        else if (ldk == 32)
-            hipLaunchKernelGGL(sstats_gather_kernel<32>, grid, dim3(256), 0, ctx->stream, c->d_seg_begin,
-                               c->d_seg_end, c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal,
-                               c->d_rfinal, ldk, c->d_partial);
-        else if (ctx->gather_rows && (ldk == 64 || ldk == 128 || ldk == 256)) {
-            const dim3 g1((unsigned)(((c->d_exec_order ? c->exec_slots : c->nseg) + 3) / 4));
-            if (ldk == 128 && ctx->gather_rows == 2)
-                hipLaunchKernelGGL((sstats_gather_bulk_kernel<2, PYLDA_GATHER_U>), g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
-                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial, c->d_exec_order);
-            else if (ldk == 256 && ctx->gather_rows == 2)
-                hipLaunchKernelGGL((sstats_gather_bulk_kernel<4, PYLDA_GATHER_U>), g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
-                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial, c->d_exec_order);
-            else if (ldk == 64)
-                hipLaunchKernelGGL(sstats_gather_rows_kernel<1>, g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
-                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial, c->d_exec_order);
-            else if (ldk == 128)
-                hipLaunchKernelGGL(sstats_gather_rows_kernel<2>, g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
-                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial, c->d_exec_order);
-            else
-                hipLaunchKernelGGL(sstats_gather_rows_kernel<4>, g1, dim3(256), 0, ctx->stream, c->d_seg_begin, c->d_seg_end,
-                                   c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal, c->d_rfinal, c->d_partial, c->d_exec_order);
-        } else
-            hipLaunchKernelGGL(sstats_gather_kernel<64>, grid, dim3(256), 0, ctx->stream, c->d_seg_begin,
-                               c->d_seg_end, c->nseg, c->d_post_doc, c->d_post_pos, c->d_tfinal,
-                               c->d_rfinal, ldk, c->d_partial);
+        if (c->wide_pos) launch_gather<int64_t>(ctx, c);
+        else launch_gather<int32_t>(ctx, c);
     }
     const int64_t total = (int64_t)ctx->V * ldk;
     const unsigned fblocks = (unsigned)((total + 255) / 256);
@@ -1021,6 +1048,8 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     } else if (!strcmp(name, "quilt_odd")) {
         ctx->quilt_odd = value != 0;
         ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "wide_postings")) {     // (takes effect for corpora whose postings are built afterwards)
+        ctx->wide_postings = value != 0;
     } else if (!strcmp(name, "lds_pad")) {
         ctx->lds_pad = (int)value;
     } else if (!strcmp(name, "quad")) {
@@ -1061,8 +1090,8 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
         if (max_terms > INT32_MAX)
             return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: a document has %lld distinct terms", (long long)max_terms);
     }
-    if (nnz > INT32_MAX)
-        return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: %lld distinct (doc, term) pairs exceed 2^31-1 per device; shard the corpus", (long long)nnz);
+    if (nnz > ((int64_t)1 << 36))       // (8 bytes of r_dn per pair alone: beyond one device's memory)
+        return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: %lld distinct (doc, term) pairs; shard the corpus", (long long)nnz);
     if (nnz > 0 && (!term_id || !term_ct))
         return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: NULL term arrays");
     int64_t tokens = 0;
@@ -1143,7 +1172,9 @@ void pylda_corpus_destroy(pylda_corpus* c)
     dev_free(c->d_doc_ptr); dev_free(c->d_term_id); dev_free(c->d_term_ct); dev_free(c->d_order);
     dev_free(c->d_gamma); dev_free(c->d_doc_ll); dev_free(c->d_doc_wll); dev_free(c->d_iters);
     dev_free(c->d_status); dev_free(c->d_flag_list); dev_free(c->d_flag_count); dev_free(c->d_scalars); dev_free(c->d_entropy_partial);
-    dev_free(c->d_tfinal); dev_free(c->d_rfinal); dev_free(c->d_term_scratch); dev_free(c->d_post_doc); dev_free(c->d_post_pos);
+    dev_free(c->d_tfinal); dev_free(c->d_rfinal); dev_free(c->d_term_scratch); dev_free(c->d_post_doc);
+    if (c->d_post_pos) (void)hipFree(c->d_post_pos);
+    c->d_post_pos = nullptr;
     dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial); dev_free(c->d_exec_order);
     delete c;
 }

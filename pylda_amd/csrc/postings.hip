@@ -14,14 +14,16 @@ namespace pylda {
 
 namespace {
 
-__global__ __launch_bounds__(256) void iota_kernel(int32_t* out, int64_t n)
+template <typename P>
+__global__ __launch_bounds__(256) void iota_kernel(P* out, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = (int32_t)i;
+    if (i < n) out[i] = (P)i;
 }
 
 // post_doc[i] = the document whose CSR range holds position post_pos[i]
-__global__ __launch_bounds__(256) void doc_of_position_kernel(const int32_t* __restrict__ post_pos, int64_t n,
+template <typename P>
+__global__ __launch_bounds__(256) void doc_of_position_kernel(const P* __restrict__ post_pos, int64_t n,
                                                               const int64_t* __restrict__ doc_ptr, int64_t D,
                                                               int32_t* __restrict__ post_doc)
 {
@@ -52,13 +54,13 @@ __global__ __launch_bounds__(256) void first_posting_kernel(const int32_t* __res
     col_ptr[v] = lo;
 }
 
-}  // namespace
-
-hipError_t build_postings_device(hipStream_t stream, int V, int64_t D, int64_t nnz, const int64_t* d_doc_ptr,
-                                 const int32_t* d_term_id, int32_t* d_post_doc, int32_t* d_post_pos,
-                                 int64_t* h_col_ptr, const char** what)
+template <typename P>
+hipError_t build_postings_typed(hipStream_t stream, int V, int64_t D, int64_t nnz, const int64_t* d_doc_ptr,
+                                const int32_t* d_term_id, int32_t* d_post_doc, P* d_post_pos,
+                                int64_t* h_col_ptr, const char** what)
 {
-    int32_t *d_sorted = nullptr, *d_iota = nullptr;
+    int32_t* d_sorted = nullptr;
+    P* d_iota = nullptr;
     int64_t* d_col = nullptr;
     void* d_temp = nullptr;
     hipError_t e = hipSuccess;
@@ -71,11 +73,11 @@ hipError_t build_postings_device(hipStream_t stream, int V, int64_t D, int64_t n
     };
     const size_t n = (size_t)(nnz > 0 ? nnz : 1);
     step(hipMalloc((void**)&d_sorted, n * sizeof(int32_t)), "postings: hipMalloc");
-    step(hipMalloc((void**)&d_iota, n * sizeof(int32_t)), "postings: hipMalloc");
+    step(hipMalloc((void**)&d_iota, n * sizeof(P)), "postings: hipMalloc");
     step(hipMalloc((void**)&d_col, ((size_t)V + 1) * sizeof(int64_t)), "postings: hipMalloc");
     if (e == hipSuccess && nnz > 0) {
         const unsigned blocks = (unsigned)((nnz + 255) / 256);
-        hipLaunchKernelGGL(iota_kernel, dim3(blocks), dim3(256), 0, stream, d_iota, nnz);
+        hipLaunchKernelGGL(iota_kernel<P>, dim3(blocks), dim3(256), 0, stream, d_iota, nnz);
         int end_bit = 1;
         while (end_bit < 31 && (1ll << end_bit) < (int64_t)V) ++end_bit;
         size_t temp_bytes = 0;
@@ -86,7 +88,7 @@ hipError_t build_postings_device(hipStream_t stream, int V, int64_t D, int64_t n
             step(rocprim::radix_sort_pairs(d_temp, temp_bytes, d_term_id, d_sorted, d_iota, d_post_pos, (size_t)nnz, 0,
                                            (unsigned)end_bit, stream), "postings: radix sort");
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(doc_of_position_kernel, dim3(blocks), dim3(256), 0, stream, d_post_pos, nnz, d_doc_ptr, D,
+            hipLaunchKernelGGL(doc_of_position_kernel<P>, dim3(blocks), dim3(256), 0, stream, d_post_pos, nnz, d_doc_ptr, D,
                                d_post_doc);
             step(hipGetLastError(), "postings: kernel launch");
         }
@@ -102,6 +104,19 @@ hipError_t build_postings_device(hipStream_t stream, int V, int64_t D, int64_t n
     if (d_col) (void)hipFree(d_col);
     if (d_temp) (void)hipFree(d_temp);
     return e;
+}
+
+}  // namespace
+
+hipError_t build_postings_device(hipStream_t stream, int V, int64_t D, int64_t nnz, const int64_t* d_doc_ptr,
+                                 const int32_t* d_term_id, int32_t* d_post_doc, void* d_post_pos, bool wide_positions,
+                                 int64_t* h_col_ptr, const char** what)
+{
+    if (wide_positions)
+        return build_postings_typed<int64_t>(stream, V, D, nnz, d_doc_ptr, d_term_id, d_post_doc,
+                                             static_cast<int64_t*>(d_post_pos), h_col_ptr, what);
+    return build_postings_typed<int32_t>(stream, V, D, nnz, d_doc_ptr, d_term_id, d_post_doc,
+                                         static_cast<int32_t*>(d_post_pos), h_col_ptr, what);
 }
 
 }  // namespace pylda

@@ -27,10 +27,11 @@ namespace pylda {
 constexpr int kSegment = 256;
 
 // LR = lanes along topics (16, 32 or 64); 64 / LR postings are handled side by side.
-template <int LR>
+// P: type of a CSR position (int32_t; int64_t for corpora of 2^31 or more (document, term) pairs).
+template <int LR, typename P>
 __global__ __launch_bounds__(256) void sstats_gather_kernel(
     const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end, int64_t nseg,
-    const int32_t* __restrict__ post_doc, const int32_t* __restrict__ post_pos,
+    const int32_t* __restrict__ post_doc, const P* __restrict__ post_pos,
     const double* __restrict__ tfinal, const double* __restrict__ rfinal, int ldk,
     double* __restrict__ partial)
 {
@@ -70,10 +71,10 @@ __global__ __launch_bounds__(256) void sstats_gather_kernel(
 // block after block: the t rows a CU gathers are then hits in ITS L2 instead of reads over the fabric (the
 // unblocked gather runs at the fabric's ~6.7 TB/s for L2 misses, wherever the rows live).  The price is one
 // partial row per (term, block): worth it while a pair holds >= 8 postings (cfg 3: 12; cfg 4: 3 - unblocked).
-template <int NCH>
+template <int NCH, typename P>
 __global__ __launch_bounds__(256) void sstats_gather_rows_kernel(
     const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end, int64_t nseg,
-    const int32_t* __restrict__ post_doc, const int32_t* __restrict__ post_pos,
+    const int32_t* __restrict__ post_doc, const P* __restrict__ post_pos,
     const double* __restrict__ tfinal, const double* __restrict__ rfinal, double* __restrict__ partial,
     const int32_t* __restrict__ exec_order)
 {
@@ -114,10 +115,10 @@ __global__ __launch_bounds__(256) void sstats_gather_rows_kernel(
 // its segment at once (lane l: document, position, then r), then walks them with the document and r of posting p
 // read from lane p (v_readlane: scalar row base + lane offset, scalar multiplier), U rows in flight per wavefront,
 // 16 bytes per lane and load.  Topic of (lane, piece j, half c): 128 j + 2 lane + c.  Fixed summation order.
-template <int NCH, int U>
+template <int NCH, int U, typename P>
 __global__ __launch_bounds__(256) void sstats_gather_bulk_kernel(
     const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end, int64_t nseg,
-    const int32_t* __restrict__ post_doc, const int32_t* __restrict__ post_pos,
+    const int32_t* __restrict__ post_doc, const P* __restrict__ post_pos,
     const double* __restrict__ tfinal, const double* __restrict__ rfinal, double* __restrict__ partial,
     const int32_t* __restrict__ exec_order)
 {

@@ -625,3 +625,32 @@ def test_fused_streaming_kernel_above_512_topics(capi, K, V, lengths):
     assert abs(ctx.estep_results(corpus)[0] - full["document_log_likelihood"]) < 1e-10 * abs(full["document_log_likelihood"])
     corpus.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("K,rows,blocks", [(10, 2, 0), (20, 2, 0), (50, 1, 0), (128, 2, 16), (128, 1, 8), (256, 2, 8),
+                                           (256, 0, 0), (300, 2, 0)])
+def test_sixty_four_bit_posting_positions(capi, ap_train, K, rows, blocks):
+    """Corpora of 2^31 or more (document, term) pairs address r_dn through 64-bit CSR positions in the postings
+    (automatic from that size; such a corpus does not fit a test).  Option wide_postings runs the same code -
+    device radix sort of (term, int64 position) pairs, every gather kernel - on a small corpus: the statistics are
+    bitwise those of the 32-bit path."""
+    g = ap_train
+    rng = np.random.default_rng(K)
+    ptr = g["doc_ptr"][:301]
+    tid, tct = g["term_id"][:ptr[-1]], g["term_ct"][:ptr[-1]]
+    eta = rng.gamma(100.0, 0.01, (K, 6806))
+    alpha = rng.uniform(0.05, 1.0, K)
+    got = []
+    for wide in (0, 1):
+        ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_rows", rows)
+        ctx.set_option("gather_blocks", blocks)
+        ctx.set_option("wide_postings", wide)
+        corpus = ctx.corpus(ptr, tid, tct)
+        res = ctx.estep_host(corpus, alpha, eta)
+        got.append(res)
+        corpus.close()
+        ctx.close()
+    assert np.array_equal(got[0]["sstats"], got[1]["sstats"])
+    assert got[0]["document_log_likelihood"] == got[1]["document_log_likelihood"]
+    assert abs(got[1]["sstats"].sum() - tct.sum()) < 1e-7
