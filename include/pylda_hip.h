@@ -49,7 +49,8 @@ typedef enum pylda_status {
  *      pylda_set_stream(NULL) = HIP's null stream (pylda_use_own_stream restores the private one)
  *   3  additions only: pylda_abi_version, pylda_mstep_enqueue / pylda_outer_device / pylda_allreduce_outer /
  *      pylda_outer_fetch (one host wait per outer iteration), pylda_model_checkpoint, pylda_mark_time /
- *      pylda_elapsed_ms, pylda_work_counters; pylda_set_alpha no longer waits for the stream
+ *      pylda_elapsed_ms, pylda_work_counters, pylda_host_alloc / pylda_host_free; pylda_set_alpha no longer waits
+ *      for the stream
  * A host compiled against another version must refuse to run: compare PYLDA_ABI_VERSION with
  * pylda_abi_version() right after loading the library. */
 #define PYLDA_ABI_VERSION 3
@@ -193,6 +194,13 @@ void* pylda_outer_device(pylda_ctx* ctx, int64_t* n_reduce);
 int pylda_allreduce_outer(pylda_ctx* ctx);
 int pylda_outer_fetch(pylda_ctx* ctx, double* document_log_likelihood, double* number_of_documents,
                       int64_t* logspace_documents, double* topic_log_likelihood, double* alpha_ss_k);
+
+/* Page-locked host memory for the arrays of the public e_step() / m_step() contract (eta, the sufficient
+ * statistics and gamma as host ndarrays, variational_bayes.py:212-216): buffers from here move at the PCIe rate
+ * (~50 GB/s) instead of through the runtime's staging copy of pageable memory (cfg 3: e_step() 52 -> about 25 ms).
+ * Any host pointer is still accepted everywhere; this is an allocator, not a requirement. */
+int pylda_host_alloc(int64_t bytes, void** out);
+int pylda_host_free(void* p);
 
 /* Device-side model checkpoint: restore = 0 saves eta (the model; the counterpart of the reference's
  * snapshot pickles, launch_train.py:203-204, without the trip through the host), restore = 1 puts the saved

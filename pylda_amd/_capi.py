@@ -60,6 +60,8 @@ SIGNATURES = {
     "pylda_outer_device": (_vp, [_vp, _c_int64_p]),
     "pylda_allreduce_outer": (ctypes.c_int, [_vp]),
     "pylda_outer_fetch": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_int64_p, _c_double_p, _c_double_p]),
+    "pylda_host_alloc": (ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(_vp)]),
+    "pylda_host_free": (ctypes.c_int, [_vp]),
     "pylda_model_checkpoint": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pylda_mark_time": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pylda_elapsed_ms": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _c_double_p]),
@@ -140,6 +142,53 @@ def _f64(a, shape=None, name="array"):
     if shape is not None and a.shape != tuple(shape):
         raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
     return a
+
+
+class _PinnedBlock(object):
+    """A page-locked host allocation exposed to numpy (array interface); goes back to the pool when the last
+    array viewing it is garbage-collected."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            _pinned_release(self.ptr, self.nbytes)
+        except Exception:
+            pass
+
+
+_pinned_pool = {}            # nbytes -> [free pointers]; at most _PINNED_KEEP per size are kept for reuse
+_PINNED_KEEP = 3
+
+
+def _pinned_release(ptr, nbytes):
+    free = _pinned_pool.setdefault(nbytes, [])
+    if len(free) < _PINNED_KEEP:
+        free.append(ptr)
+    elif _lib is not None:
+        _lib.pylda_host_free(_vp(ptr))
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy.empty in page-locked host memory (pylda_host_alloc): the arrays e_step() / m_step() hand back and
+    forth move at the PCIe rate.  Recycled through a small pool - page-locking 50 MB costs milliseconds."""
+    lib = load()
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    if nbytes == 0:
+        return np.empty(shape, dtype=dtype)
+    free = _pinned_pool.get(nbytes)
+    if free:
+        ptr = free.pop()
+    else:
+        handle = _vp()
+        rc = lib.pylda_host_alloc(nbytes, ctypes.byref(handle))
+        if rc != 0:                          # (no page-locked memory left: ordinary memory works everywhere)
+            return np.empty(shape, dtype=dtype)
+        ptr = handle.value
+    return np.asarray(_PinnedBlock(ptr, nbytes)).view(dtype).reshape(shape)
 
 
 class PyldaError(RuntimeError):
@@ -239,7 +288,7 @@ class Context(object):
         self._check(self._lib.pylda_set_eta(self._h, _dp(_f64(eta, (self.K, self.V), "eta"))))
 
     def get_eta(self):
-        out = np.empty((self.K, self.V), dtype=np.float64)
+        out = pinned_empty((self.K, self.V))
         self._check(self._lib.pylda_get_eta(self._h, _dp(out)))
         return out
 
@@ -275,7 +324,7 @@ class Context(object):
         return ll.value, wll.value, nlog.value
 
     def get_sstats(self):
-        out = np.empty((self.K, self.V), dtype=np.float64)
+        out = pinned_empty((self.K, self.V))
         self._check(self._lib.pylda_get_sstats(self._h, _dp(out)))
         return out
 
@@ -283,7 +332,7 @@ class Context(object):
         self._check(self._lib.pylda_set_sstats(self._h, _dp(_f64(sstats, (self.K, self.V), "sstats"))))
 
     def get_gamma(self, corpus):
-        out = np.empty((corpus.D, self.K), dtype=np.float64)
+        out = pinned_empty((corpus.D, self.K))
         self._check(self._lib.pylda_get_gamma(self._h, corpus._h, _dp(out)))
         return out
 

@@ -126,6 +126,7 @@ struct pylda_ctx {
     int quilt12 = 0;
     int gather_rows = 2;            // 0: 64-topic chunks; 1: whole rows (ldk 64 / 128 / 256); 2: + postings in bulk (ldk 128 / 256)
     int gather_blocks = -1;         // document blocks of the gather: -1 automatic, 0 / 1 off, n forced (multiple of 8)
+    int slab_uber = 1;              // small corpora: all slab launch classes in one dispatch
     int wide_postings = 0;          // test hook: 64-bit CSR positions in the postings whatever nnz (automatic from 2^31 pairs)
     int lds_pad = 0;                // A/B: extra dynamic LDS per quad workgroup (forces one workgroup per CU)
     int quad = 1;                   // register + LDS tile kernel (estep_quad.h) for table strides 128 / 256, N <= 208
@@ -457,6 +458,66 @@ int launch_slab_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 #undef SLAB_RN32
 #undef SLAB_CASE
     return fail(ctx, PYLDA_ERR_STATE, "no slab kernel for W=%d RK=%d RN=%d", W, L.rk, L.rn);
+}
+
+// The slab classes of a small corpus as ONE dispatch (estep_slab.h, estep_slab_uber_kernel): the classes from index
+// `from` to the end of the plan, or -1.  Eligible: at least two classes, all of the slab family with the same slab
+// width and at most 4 words per lane at 16-topic slabs (the 6-word instantiation needs more than 256 registers: one
+// wavefront per SIMD - it would halve the residency of everybody), every wavefront resident at once at two per SIMD.
+int slab_uber_from(const pylda_ctx* ctx, const pylda_corpus* c)
+{
+    if (!ctx->slab_uber || c->plan.size() < 2) return -1;
+    int from = (int)c->plan.size();
+    const int rk = c->plan.back().rk;
+    int64_t docs = 0;
+    while (from > 0) {
+        const Launch& L = c->plan[(size_t)from - 1];
+        if (L.variant != kSlab || L.rk != rk || (rk == 16 && L.rn > 4) || (rk == 32 && L.rn > 2)) break;
+        docs += L.count;
+        --from;
+    }
+    const int W = ctx->ldk / std::max(1, rk);
+    // (8 wavefronts x 16-topic slabs: the combined kernel spills)
+    if ((int)c->plan.size() - from < 2 || (int)c->plan.size() - from > 6 || W > 4 || docs * W > (int64_t)ctx->num_cu * 4 * 2) return -1;
+    return from;
+}
+
+template <int W, int RK>
+int launch_slab_uber(pylda_ctx* ctx, const EstepParams& p, const pylda_corpus* c, int from)
+{
+    SlabUberClasses cls;
+    memset(&cls, 0, sizeof cls);
+    cls.n = (int)c->plan.size() - from;
+    size_t lds = 0;
+    int64_t docs = 0;
+    for (int i = 0; i < cls.n; ++i) {
+        const Launch& L = c->plan[(size_t)(from + i)];
+        cls.first[i] = (int)(L.first - c->plan[(size_t)from].first);
+        cls.rn[i] = L.rn;
+        docs += L.count;
+        // (the largest class comes first: documents are scheduled longest first)
+        const size_t need = RK == 32 ? (L.rn == 1 ? SlabLds<W, RK, 1>::total : SlabLds<W, RK, 2>::total)
+                          : L.rn == 1 ? SlabLds<W, RK, 1>::total : L.rn == 2 ? SlabLds<W, RK, 2>::total
+                          : L.rn == 3 ? SlabLds<W, RK, 3>::total : L.rn == 4 ? SlabLds<W, RK, 4>::total : SlabLds<W, RK, 6>::total;
+        lds = std::max(lds, need);
+    }
+    cls.first[cls.n] = (int)docs;
+    auto kern = estep_slab_uber_kernel<W, RK>;
+    if (lds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)docs), dim3(kWave * W), lds, ctx->stream, p, cls);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
+int launch_slab_uber_any(pylda_ctx* ctx, const EstepParams& p, const pylda_corpus* c, int from)
+{
+    const int rk = c->plan[(size_t)from].rk, W = ctx->ldk / rk;
+#define UBER_CASE(w_, rk_) if (W == w_ && rk == rk_) return launch_slab_uber<w_, rk_>(ctx, p, c, from);
+    UBER_CASE(1, 32) UBER_CASE(2, 32) UBER_CASE(4, 32)
+    UBER_CASE(1, 16) UBER_CASE(2, 16) UBER_CASE(4, 16)
+#undef UBER_CASE
+    return fail(ctx, PYLDA_ERR_STATE, "no slab uber kernel for W=%d RK=%d", W, rk);
 }
 
 template <int W, int KRL, int RWL>
@@ -1048,6 +1109,8 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     } else if (!strcmp(name, "quilt_odd")) {
         ctx->quilt_odd = value != 0;
         ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "slab_uber")) {
+        ctx->slab_uber = value != 0;
     } else if (!strcmp(name, "wide_postings")) {     // (takes effect for corpora whose postings are built afterwards)
         ctx->wide_postings = value != 0;
     } else if (!strcmp(name, "lds_pad")) {
@@ -1318,8 +1381,12 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     } else {
         hipStream_t main_stream = ctx->stream;
-        const bool fan_out = c->plan.size() > 1;
-        const int used = fan_out ? (int)std::min<size_t>(pylda_ctx::kAux, c->plan.size()) : 0;
+        // a small corpus' slab classes go out as one dispatch on the main stream (no fork / join at all when that is
+        // the whole plan); everything else: one launch per class, fanned out over the auxiliary streams
+        const int uber_from = slab_uber_from(ctx, c);
+        const size_t separate = uber_from >= 0 ? (size_t)uber_from : c->plan.size();
+        const bool fan_out = separate > (uber_from >= 0 ? 0u : 1u);
+        const int used = fan_out ? (int)std::min<size_t>(pylda_ctx::kAux, separate) : 0;
         if (fan_out) {
             HIP_TRY(ctx, hipEventRecord(ctx->fork_event, main_stream));
             for (int i = 0; i < used; ++i) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream[i], ctx->fork_event, 0));
@@ -1334,6 +1401,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         size_t launch_index = 0;
         for (const Launch& L : c->plan) {
             const int slot = (int)launch_index;
+            if (launch_index >= separate) break;
             if (fan_out) ctx->stream = ctx->aux_stream[launch_index % pylda_ctx::kAux];
             ++launch_index;
             p.order = c->d_order + L.first;
@@ -1356,6 +1424,20 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             default: rc = launch_generic<256, 1>(ctx, p, L); break;
             }
             close_bracket(class_bracket, ctx->stream);
+            if (rc != PYLDA_OK) {
+                join();
+                return rc;
+            }
+        }
+        ctx->stream = main_stream;
+        if (uber_from >= 0) {
+            const Launch& L = c->plan[(size_t)uber_from];
+            p.order = c->d_order + L.first;
+            p.n_cap = L.n_cap;
+            p.tile_stride = L.tile_stride;
+            const int class_bracket = open_bracket(uber_from, main_stream);      // (the group's time is booked on its first class)
+            rc = launch_slab_uber_any(ctx, p, c, uber_from);
+            close_bracket(class_bracket, main_stream);
             if (rc != PYLDA_OK) {
                 join();
                 return rc;
@@ -1647,6 +1729,24 @@ int pylda_outer_fetch(pylda_ctx* ctx, double* document_log_likelihood, double* n
     if (logspace_documents) *logspace_documents = (int64_t)std::llround(host[2]);
     if (alpha_ss_k) memcpy(alpha_ss_k, host + 4, (size_t)K * sizeof(double));
     if (topic_log_likelihood) *topic_log_likelihood = topic_ll_from(ctx, host + 4 + K);
+    return PYLDA_OK;
+}
+
+int pylda_host_alloc(int64_t bytes, void** out)
+{
+    if (!out || bytes < 0) return PYLDA_ERR_INVALID;
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(nullptr, e == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, "host_alloc: %s", hipGetErrorString(e));
+    }
+    return PYLDA_OK;
+}
+
+int pylda_host_free(void* p)
+{
+    if (p && hipHostFree(p) != hipSuccess) return fail(nullptr, PYLDA_ERR_HIP, "host_free: not a pylda_host_alloc pointer");
     return PYLDA_OK;
 }
 

@@ -40,15 +40,15 @@ struct SlabLds {
     static constexpr size_t total = ((misc + (size_t)8 * W * 8) + 15) & ~(size_t)15;
 };
 
+// One document on the calling workgroup (W wavefronts); `smem` holds SlabLds<W, RK, RN>::total bytes.
 template <int W, int RK, int RN>
-__global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
+__device__ __forceinline__ void slab_document(const EstepParams& p, const int doc, char* smem)
 {
     using L = SlabLds<W, RK, RN>;
     constexpr int NT = kWave * W;
     constexpr int LP = kWave / RK;          // lanes that share one topic in the gamma update
     constexpr int Q = RK / 4;               // values per lane after the two swap levels
     static_assert(RK == 16 || RK == 32, "slab width");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     double* partial = reinterpret_cast<double*>(smem + L::partial);
     double* red = reinterpret_cast<double*>(smem + L::red);
     unsigned long long* chg = reinterpret_cast<unsigned long long*>(smem + L::chg);   // [2], 2^40 fixed point
@@ -58,7 +58,6 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
     const int lane = tid & (kWave - 1);
     const int wave = tid / kWave;
     const int K = p.K, ldk = p.ldk;
-    const int doc = p.order[blockIdx.x];
     const int64_t lo = p.doc_ptr[doc];
     const int N = (int)(p.doc_ptr[doc + 1] - lo);
     const int k0 = wave * RK;
@@ -283,6 +282,48 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
         p.doc_words_ll[doc] = p.heldout ? t1 + sh - tl : 0.0;            // :204
         p.iters[doc] = it;
         p.status[doc] = 0;
+    }
+}
+
+template <int W, int RK, int RN>
+__global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    slab_document<W, RK, RN>(p, p.order[blockIdx.x], smem);
+}
+
+// Small corpora: every launch class of the slab family in ONE dispatch.  A corpus of a few thousand documents
+// (associated-press: 2000 documents in five words-per-lane classes) cannot fill the chip; run as five kernels
+// on five streams it pays the fork / join over the streams (2-3 x the slowest class, profiles/r01_ap_k10_summary.txt)
+// for nothing: all its wavefronts are resident at once even at the register budget of the largest class.  The
+// workgroup picks its instantiation from its position in the (longest first) schedule; the switch is uniform.
+struct SlabUberClasses {
+    int n;            // classes
+    int first[7];     // class i holds workgroups first[i] .. first[i + 1] - 1
+    int rn[6];        // ... and runs RN = rn[i] words per lane
+};
+
+template <int W, int RK>
+__global__ __launch_bounds__(kWave* W) void estep_slab_uber_kernel(EstepParams p, SlabUberClasses cls)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    int rn = cls.rn[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i)
+        if (i < cls.n && b >= cls.first[i]) rn = cls.rn[i];
+    const int doc = p.order[b];
+    if constexpr (RK == 32) {
+        if (rn == 1) slab_document<W, RK, 1>(p, doc, smem);
+        else slab_document<W, RK, 2>(p, doc, smem);
+    } else {
+        switch (rn) {
+        case 1: slab_document<W, RK, 1>(p, doc, smem); break;
+        case 2: slab_document<W, RK, 2>(p, doc, smem); break;
+        case 3: slab_document<W, RK, 3>(p, doc, smem); break;
+        case 4: slab_document<W, RK, 4>(p, doc, smem); break;
+        default: slab_document<W, RK, 6>(p, doc, smem); break;
+        }
     }
 }
 
