@@ -181,7 +181,9 @@ __device__ __forceinline__ double exp_digamma_minus_with(double x, double c, con
     const double p45 = fma(w, k.b6, k.b5);
     const double e0 = fma(p23, w2, p01), e1 = fma(k.b1, w2, p45);
     const double series = fma(e1, w4, e0) * w;
-    const double tail = fma(-0.5, inv, -series) - (shift + c);     // psi(x) - log(y) - c
+    // (the clamp: x below ~1e-50 makes the exponent -1/x too large for exp's argument reduction, or -inf; the
+    //  result is a clean 0 either way)
+    const double tail = fmax(fma(-0.5, inv, -series) - (shift + c), -1100.0);     // psi(x) - log(y) - c
     return y * k.exp_of(tail);
 }
 
@@ -373,6 +375,10 @@ __device__ __forceinline__ double exp_digamma_minus_levels(double x, double c, c
     tail = tail - c;                                            // 15
     PYLDA_LEVEL();
     tail = fma(-nt, rd, tail);                                  // 16   psi(x) - log y - c
+    PYLDA_LEVEL();
+    // x below ~1e-50 (an alpha_k that small: pylda_set_alpha accepts any positive value) makes the exponent -1/x so
+    // large that the reduced argument below is garbage (or -inf - -inf): exp of anything under -745 is 0 anyway
+    tail = fmax(tail, -1100.0);                                 // 16'
     PYLDA_LEVEL();
     const double kx = tail * log2e;                             // 17
     PYLDA_LEVEL();

@@ -76,6 +76,12 @@ def test_device_fused_exp_digamma(capi):
         psi = g["psi"][(g["x"] > 1e-4) & (g["x"] < 1e5)]
         # the exponent psi - c carries ~1 ulp of ITS magnitude: |psi| ~ 1e3 at x ~ 1e-3 costs 3 digits
         assert np.all(np.abs(got[ok] - want[ok]) / want[ok] < 2e-15 * (4.0 + np.abs(psi[ok] - c)))
+    # arguments far below anything gamma takes in practice (gamma_k >= alpha_k, and pylda_set_alpha accepts any
+    # positive alpha): exp(psi(x) - c) = exp(-1/x - ...) is a clean 0 in BOTH fused forms, never inf / NaN
+    tiny_x = np.array([1e-300, 1e-250, 1e-170, 1e-100, 1e-60, 1e-40, 1e-20, 1e-10, 1e-5])
+    for c in (0.0, 4.0, 2000.0 + 3.0):          # (c > 1e3 selects the level-ordered form the kernels' gamma phase uses)
+        got = ctx.test_expdigamma(tiny_x, c)
+        assert np.array_equal(got, np.zeros_like(tiny_x)), (c, got)
     ctx.close()
 
 
