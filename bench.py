@@ -285,10 +285,13 @@ def measure(job, args, name, steps, warmup, docs=None):
     # alpha and the counter on the host) INSIDE the timed region - every step runs the whole E-step, exchange and
     # M-step, nothing is cached.  --warmup beyond 3 runs further window steps untimed.
     t_first = time.perf_counter()
+    t_step1 = None
     for _ in range(PROTOCOL_WARMUP):
         vb.learning()
+        if t_step1 is None:
+            t_step1 = time.perf_counter() - t_first          # includes the one-off postings (CSC) build of the first E-step
     job.torch.cuda.synchronize()
-    t_first = time.perf_counter() - t_first      # includes the one-off postings (CSC) build of the first E-step
+    t_first = time.perf_counter() - t_first
     ctx.model_checkpoint()
     alpha_ckpt, counter_ckpt = vb._alpha_alpha.copy(), vb._counter
 
@@ -366,7 +369,10 @@ def measure(job, args, name, steps, warmup, docs=None):
                      "kernel_ms": kernel_ms, "kernel_ms_documents": doc_ms, "kernel_ms_sstats": ss_ms,
                      "algorithmic_bytes": B, "launch_classes": classes,
                      "statistics_gather": {"document_blocks": vb._train_corpus.layout("gather_blocks"),
-                                           "segments": vb._train_corpus.layout("gather_segments")}},
+                                           "segments": vb._train_corpus.layout("gather_segments"),
+                                           "rounds": vb._train_corpus.layout("gather_rounds"),
+                                           "partial_row_bytes": vb._train_corpus.layout("gather_partial_rows") * 8 *
+                                           ctx_table_stride(ctx)}},
         # the honest companion: the document kernels are fp64-VALU / latency bound, not HBM bound;
         # flops = 4 K sum_d I_d N_d of the inner iterations executed IN THE TIMED WINDOW (device counters)
         "roofline_fp64": {"bound": "fp64 vector FMA", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
@@ -374,7 +380,7 @@ def measure(job, args, name, steps, warmup, docs=None):
                           "mean_inner_iterations": sum_iters / calls / max(1, D_local)},
         "joint_log_likelihood": joint,
         "startup": {"generate_corpus_s": t_gen, "upload_and_schedule_s": t_init,
-                    "first_%d_steps_s" % PROTOCOL_WARMUP: t_first,
+                    "first_step_s": t_step1, "first_%d_steps_s" % PROTOCOL_WARMUP: t_first,
                     "note": "the first E-step also builds the corpus' postings (CSC) for the statistics gather"},
     }
     expected = EXPECTED_CHECKSUM.get(name)
@@ -439,6 +445,10 @@ def host_contract_leg(vb):
         gc.collect()
     return {"e_step_ms": best_e, "m_step_ms": best_m,
             "note": "public e_step() / m_step() with host ndarrays (sufficient statistics K x V down and up again), best of 3"}
+
+
+def ctx_table_stride(ctx):
+    return int(ctx._lib.pylda_table_stride(ctx._h))
 
 
 def release(vb):

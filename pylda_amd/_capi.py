@@ -485,7 +485,9 @@ class Corpus(object):
         self._h = handle
         self.D = int(doc_ptr.size - 1)
         self.nnz = int(term_id.size)
-        self.tokens = int(term_ct.sum())
+        tokens = ctypes.c_int64(0)
+        ctx._lib.pylda_corpus_info(handle, None, None, ctypes.byref(tokens), None)      # (summed while validating)
+        self.tokens = int(tokens.value)
 
     def gamma_device_ptr(self):
         return int(self._ctx._lib.pylda_gamma_device(self._h) or 0)

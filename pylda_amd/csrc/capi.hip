@@ -8,13 +8,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "comm.h"
@@ -126,6 +129,7 @@ struct pylda_ctx {
     int quilt12 = 0;
     int gather_rows = 2;            // 0: 64-topic chunks; 1: whole rows (ldk 64 / 128 / 256); 2: + postings in bulk (ldk 128 / 256)
     int gather_blocks = -1;         // document blocks of the gather: -1 automatic, 0 / 1 off, n forced (multiple of 8)
+    int gather_round_mb = 0;        // budget of the gather's partial rows per round, MiB (0: 4 GiB)
     int slab_uber = 1;              // small corpora: all slab launch classes in one dispatch
     int wide_postings = 0;          // test hook: 64-bit CSR positions in the postings whatever nnz (automatic from 2^31 pairs)
     int lds_pad = 0;                // A/B: extra dynamic LDS per quad workgroup (forces one workgroup per CU)
@@ -177,6 +181,12 @@ struct pylda_corpus {
     int64_t* d_seg_end = nullptr;
     int32_t* d_exec_order = nullptr;   // document-blocked gather: segment of every (workgroup, wavefront) slot, or -1
     int64_t exec_slots = 0;
+    // The gather runs in ROUNDS over contiguous term ranges that share one set of partial rows (a (term, block)
+    // pair costs a row: 45 GB at cfg 4 in one go - and a second for the allocation alone): gather round r, finalize
+    // its terms, reuse the rows.  One round unless the rows would exceed the budget.
+    struct Round { int64_t seg_lo, seg_hi; int w_first, n_words; int64_t slot_lo, slot_count; int64_t ent_first, ent_blocks; };
+    std::vector<Round> rounds;
+    int64_t partial_rows = 0, ent_blocks = 0;
     int gather_blocks = 1;
     int64_t* d_word_seg_ptr = nullptr;  // V+1
     double* d_partial = nullptr;   // nseg x ldk
@@ -226,6 +236,19 @@ void dev_free(T*& p)
     if (p) (void)hipFree(p);
     p = nullptr;
 }
+
+// PYLDA_TIMING=1: wall time of the one-off phases (corpus upload, postings, segment cut) on stderr
+struct PhaseTimer {
+    bool on = getenv("PYLDA_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pylda timing] %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
+        t0 = now;
+    }
+};
 
 int tile_stride_for(int K) { return K | 1; }   // odd => conflict-free ds_read_b64 along words
 
@@ -377,44 +400,47 @@ void build_plan(pylda_corpus* c)
     c->plan_epoch = ctx->plan_epoch;
     c->plan_exact = ctx->exact_stop;
     const int64_t D = c->D;
-    int64_t i = 0;
-    while (i < D) {
-        // documents are sorted by distinct-term count, descending: a launch is a
-        // maximal run with the same variant whose LDS request (sized for its first,
-        // largest document) is not more than ~25 % above what its last needs.
-        size_t lds_first;
-        const int v = choose_variant(ctx, c->h_terms_sorted[i], &lds_first);
+    // Documents are sorted by distinct-term count, descending, and the kernel choice depends on that count only:
+    // walk the RUNS of equal counts (a few hundred at most), not the documents (10^6 at cfg 4).
+    struct Run { int64_t first, count; int n; int variant; size_t lds; int sub; int rk; };
+    std::vector<Run> runs;
+    for (int64_t i = 0; i < D;) {
+        const int n = c->h_terms_sorted[(size_t)i];
         int64_t j = i + 1;
-        while (j < D) {
-            size_t lds_j;
-            const int vj = choose_variant(ctx, c->h_terms_sorted[j], &lds_j);
-            if (vj != v) break;
-            if (v == kQuilt && quilt_rwl_for(ctx, c->h_terms_sorted[j]) != quilt_rwl_for(ctx, c->h_terms_sorted[i])) break;
-            if (v == kQuad && quad_geom_for(ctx, c->h_terms_sorted[j]) != quad_geom_for(ctx, c->h_terms_sorted[i])) break;
-            if (v == kQwide && qwide_rounds_for(c->h_terms_sorted[j]) != qwide_rounds_for(c->h_terms_sorted[i])) break;
-            if (v == kSlab) {
-                const SlabGeom gi = slab_geom_for(ctx, c->h_terms_sorted[i]), gj = slab_geom_for(ctx, c->h_terms_sorted[j]);
-                if (gi.RK != gj.RK || gi.RN != gj.RN) break;
-            }
-            if (v != kGenericGlobal && lds_first > 4096 && lds_j * 5 < lds_first * 4 &&
-                (j - i) >= 4 * (int64_t)ctx->num_cu)
+        while (j < D && c->h_terms_sorted[(size_t)j] == n) ++j;
+        Run r{i, j - i, n, 0, 0, 0, 0};
+        r.variant = choose_variant(ctx, n, &r.lds);
+        r.sub = r.variant == kQuilt ? quilt_rwl_for(ctx, n) : r.variant == kQuad ? quad_geom_for(ctx, n)
+              : r.variant == kQwide ? qwide_rounds_for(n) : r.variant == kSlab ? slab_geom_for(ctx, n).RN : 0;
+        r.rk = r.variant == kSlab ? slab_geom_for(ctx, n).RK : 0;
+        runs.push_back(r);
+        i = j;
+    }
+    for (size_t a = 0; a < runs.size();) {
+        // a launch is a maximal sequence of runs with the same variant and geometry whose LDS request (sized for
+        // its first, largest document) is not more than ~25 % above what its last needs
+        const Run& first = runs[a];
+        size_t b = a + 1;
+        int64_t docs = first.count;
+        while (b < runs.size()) {
+            const Run& r = runs[b];
+            if (r.variant != first.variant || r.sub != first.sub || r.rk != first.rk) break;
+            if (first.variant != kGenericGlobal && first.lds > 4096 && r.lds * 5 < first.lds * 4 && docs >= 4 * (int64_t)ctx->num_cu)
                 break;
-            ++j;
+            docs += r.count;
+            ++b;
         }
         Launch L;
-        L.variant = v;
-        L.first = i;
-        L.count = j - i;
-        L.n_cap = std::max(1, c->h_terms_sorted[i]);
+        L.variant = first.variant;
+        L.first = first.first;
+        L.count = docs;
+        L.n_cap = std::max(1, first.n);
         L.tile_stride = tile_stride_for(ctx->K);
-        L.lds_bytes = lds_first;
-        L.rn = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RN
-             : v == kQuilt ? quilt_rwl_for(ctx, c->h_terms_sorted[i])
-             : v == kQuad ? quad_geom_for(ctx, c->h_terms_sorted[i])
-             : v == kQwide ? qwide_rounds_for(c->h_terms_sorted[i]) : 0;
-        L.rk = v == kSlab ? slab_geom_for(ctx, c->h_terms_sorted[i]).RK : 0;
+        L.lds_bytes = first.lds;
+        L.rn = first.sub;
+        L.rk = first.rk;
         c->plan.push_back(L);
-        i = j;
+        a = b;
     }
 }
 
@@ -711,6 +737,23 @@ int enqueue_prepare(pylda_ctx* ctx, bool heldout)
     return PYLDA_OK;
 }
 
+// One host thread's share of the segment cut (build_postings): the segments of a contiguous range of terms.
+struct CutPiece {
+    std::vector<int64_t> begin, end, per_word;
+    std::vector<int32_t> block, per_block;      // per_block[b]: this piece's segments in document block b
+    int v0 = 0;
+    int64_t base = 0;                           // index of its first segment in the whole list
+};
+
+template <typename F>
+void run_on_threads(int nthreads, F&& fn)
+{
+    std::vector<std::thread> workers;
+    for (int t = 1; t < nthreads; ++t) workers.emplace_back(fn, t);
+    fn(0);
+    for (auto& w : workers) w.join();
+}
+
 // Postings (CSC) of the corpus, built once, on the first training E-step, on the device (postings.hip):
 // for every word the (document, CSR position) pairs in document order, cut into segments.
 int build_postings(pylda_corpus* c)
@@ -735,8 +778,10 @@ int build_postings(pylda_corpus* c)
             dev_free(c->d_exec_order); dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial);
             c->nseg = 0;
             c->exec_slots = 0;
+            c->rounds.clear();
         }
     } undo{c};
+    PhaseTimer timer;
     c->wide_pos = ctx->wide_postings || nnz > INT32_MAX;
     A(dev_alloc(ctx, &c->d_post_doc, (size_t)nnz));
     if (rc == PYLDA_OK) {
@@ -754,6 +799,7 @@ int build_postings(pylda_corpus* c)
                                                c->d_post_pos, c->wide_pos, col_ptr.data(), &what);
     if (e != hipSuccess)
         return fail(ctx, e == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    timer.lap("postings on the device");
     std::vector<int64_t> seg_begin, seg_end, word_seg_ptr((size_t)V + 1, 0);
     seg_begin.reserve((size_t)(nnz / kSegment + V));
     seg_end.reserve((size_t)(nnz / kSegment + V));
@@ -775,35 +821,79 @@ int build_postings(pylda_corpus* c)
             const int by_l2 = std::max(8, 8 * (int)std::lround(t_bytes / (8 * 4.3e6)));
             const int by_pairs = (int)std::min<double>(1e6, (double)nnz / (8.0 * V)) / 8 * 8;
             NB = std::min(by_l2, by_pairs);
-            size_t free_b = 0, total_b = 0;
-            if (NB >= 8 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const double row = (double)ctx->ldk * sizeof(double);
-                while (NB >= 8 && ((double)V * NB + (double)nnz / kSegment) * row > 0.25 * (double)free_b) NB -= 8;
-            }
             if (NB < 8) NB = 1;
         }
     }
-    std::vector<int32_t> seg_block;
+    using Round = pylda_corpus::Round;
+    std::vector<CutPiece> pieces;
+    int cut_threads = 1;
     if (NB > 1) {
-        std::vector<int32_t> post_doc((size_t)nnz);
-        if (nnz > 0 && hipMemcpy(post_doc.data(), c->d_post_doc, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        // the documents of the postings come back through a page-locked buffer (0.8 GB at cfg 4: 16 ms instead of the
+        // pageable copy's 0.3 s) and the cut runs on all host threads, term ranges side by side (it took 0.4 s)
+        int32_t* post_doc = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&post_doc), (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
+            return fail(ctx, PYLDA_ERR_OOM, "postings: page-locked staging buffer");
+        struct Pinned { int32_t* p; ~Pinned() { (void)hipHostFree(p); } } pinned{post_doc};
+        timer.lap("page-locked staging buffer");
+        if (nnz > 0 && hipMemcpy(post_doc, c->d_post_doc, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
             return fail(ctx, PYLDA_ERR_HIP, "postings: D2H copy failed");
+        timer.lap("documents of the postings D2H");
         const int64_t per_block = (c->D + NB - 1) / NB;
-        for (int v = 0; v < V; ++v) {
-            int64_t b = col_ptr[v];
-            while (b < col_ptr[v + 1]) {
-                const int32_t blk = (int32_t)(post_doc[(size_t)b] / per_block);
-                const int64_t block_end = ((int64_t)blk + 1) * per_block;       // first document of the next block
-                const int64_t cap = std::min<int64_t>(col_ptr[v + 1], b + kSegment);
-                int64_t e = b + 1;
-                while (e < cap && post_doc[(size_t)e] < block_end) ++e;
-                seg_begin.push_back(b);
-                seg_end.push_back(e);
-                seg_block.push_back(blk);
-                b = e;
+        // (a forced round budget - tests - cuts at least 8 pieces so that small corpora get several rounds as well)
+        const int nthreads = (int)std::max<int64_t>(ctx->gather_round_mb > 0 ? 8 : 1,
+                                                    std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, nnz / 2000000 + 1}));
+        using Piece = CutPiece;
+        cut_threads = nthreads;
+        pieces.assign((size_t)nthreads, Piece());
+        run_on_threads(nthreads, [&](int t) {
+            // thread t: the terms whose postings start in its 1 / nthreads share of the posting range
+            Piece& out = pieces[(size_t)t];
+            out.per_block.assign((size_t)NB, 0);
+            const int64_t from = nnz * t / nthreads, to = nnz * (t + 1) / nthreads;
+            const int v0 = (int)(std::lower_bound(col_ptr.begin(), col_ptr.end() - 1, from) - col_ptr.begin());
+            const int v1 = t + 1 == nthreads ? V : (int)(std::lower_bound(col_ptr.begin(), col_ptr.end() - 1, to) - col_ptr.begin());
+            out.v0 = v0;
+            out.per_word.reserve((size_t)std::max(0, v1 - v0));
+            for (int v = v0; v < v1; ++v) {
+                int64_t b = col_ptr[(size_t)v], n = 0;
+                while (b < col_ptr[(size_t)v + 1]) {
+                    const int32_t blk = (int32_t)(post_doc[(size_t)b] / per_block);
+                    const int64_t block_end = ((int64_t)blk + 1) * per_block;       // first document of the next block
+                    const int64_t cap = std::min<int64_t>(col_ptr[(size_t)v + 1], b + kSegment);
+                    int64_t e = b + 1;
+                    while (e < cap && post_doc[(size_t)e] < block_end) ++e;
+                    out.begin.push_back(b);
+                    out.end.push_back(e);
+                    out.block.push_back(blk);
+                    out.per_block[(size_t)blk] += 1;
+                    b = e;
+                    ++n;
+                }
+                out.per_word.push_back(n);
             }
-            word_seg_ptr[v + 1] = (int64_t)seg_begin.size();
+        });
+        int64_t total = 0;
+        int covered = 0;
+        for (Piece& piece : pieces) {               // the pieces cover the terms in order
+            if (piece.v0 != covered) return fail(ctx, PYLDA_ERR_STATE, "postings: the segment cut lost terms at %d", covered);
+            piece.base = total;
+            total += (int64_t)piece.begin.size();
+            covered += (int)piece.per_word.size();
         }
+        if (covered != V) return fail(ctx, PYLDA_ERR_STATE, "postings: the segment cut covered %d of %d terms", covered, V);
+        seg_begin.resize((size_t)total);
+        seg_end.resize((size_t)total);
+        run_on_threads(nthreads, [&](int t) {
+            const Piece& piece = pieces[(size_t)t];
+            std::copy(piece.begin.begin(), piece.begin.end(), seg_begin.begin() + piece.base);
+            std::copy(piece.end.begin(), piece.end.end(), seg_end.begin() + piece.base);
+            int64_t at = piece.base;
+            for (size_t i = 0; i < piece.per_word.size(); ++i) {
+                at += piece.per_word[i];
+                word_seg_ptr[(size_t)piece.v0 + i + 1] = at;
+            }
+        });
+        timer.lap("segment cut");
     } else {
         for (int v = 0; v < V; ++v) {
             for (int64_t b = col_ptr[v]; b < col_ptr[v + 1]; b += kSegment) {
@@ -815,38 +905,88 @@ int build_postings(pylda_corpus* c)
     }
     c->nseg = (int64_t)seg_begin.size();
     c->gather_blocks = NB;
+    c->rounds.clear();
+    const int64_t ldk_rows = ctx->ldk;
+    auto blocks_of = [&](int n_words) { return ((int64_t)n_words * ldk_rows + 255) / 256; };
     if (NB > 1 && c->nseg > 0) {
-        // XCD x works through the segments of blocks x, x + 8, ... block after block; workgroup g (4 wavefronts)
-        // takes slots 4 * (g / 8) .. + 3 of the list of XCD g % 8
-        constexpr int kXcd = 8;
-        std::vector<std::vector<int32_t>> list(kXcd);
-        {
-            std::vector<std::vector<int32_t>> by_block((size_t)NB);
-            for (int64_t s = 0; s < c->nseg; ++s) by_block[(size_t)seg_block[(size_t)s]].push_back((int32_t)s);
-            for (int b = 0; b < NB; ++b) {
-                auto& dst = list[(size_t)(b % kXcd)];
-                dst.insert(dst.end(), by_block[(size_t)b].begin(), by_block[(size_t)b].end());
-                while (dst.size() % 4) dst.push_back(-1);         // a workgroup never mixes two blocks' rows
-            }
+        // rounds: groups of consecutive pieces (contiguous term ranges), each within the budget of partial rows
+        const double row_bytes = (double)ctx->ldk * sizeof(double);
+        const double budget = ctx->gather_round_mb > 0 ? (double)ctx->gather_round_mb * 1048576.0 : 4.0 * 1073741824.0;
+        const int64_t max_rows = std::max<int64_t>(1, (int64_t)(budget / row_bytes));
+        std::vector<std::pair<size_t, size_t>> groups;        // [first piece, last piece + 1)
+        for (size_t t = 0; t < pieces.size();) {
+            size_t u = t + 1;
+            int64_t rows = (int64_t)pieces[t].begin.size();
+            while (u < pieces.size() && rows + (int64_t)pieces[u].begin.size() <= max_rows) rows += (int64_t)pieces[u++].begin.size();
+            groups.emplace_back(t, u);
+            t = u;
         }
-        size_t longest = 0;
-        for (const auto& l : list) longest = std::max(longest, l.size());
-        const int64_t groups_per_xcd = (int64_t)(longest / 4);
-        std::vector<int32_t> order((size_t)(groups_per_xcd * kXcd * 4), -1);
-        for (int x = 0; x < kXcd; ++x)
-            for (size_t i = 0; i < list[(size_t)x].size(); ++i)
-                order[(size_t)(((int64_t)(i / 4) * kXcd + x) * 4 + (int64_t)(i % 4))] = list[(size_t)x][i];
+        // XCD x works through the segments of blocks x, x + 8, ... block after block; workgroup g (4 wavefronts)
+        // takes slots 4 * (g / 8) .. + 3 of the list of XCD g % 8.  A block's segments keep their order (term by term);
+        // a block starts on a multiple of 4 slots (a workgroup never mixes two blocks' rows).  One such order per round.
+        constexpr int kXcd = 8;
+        std::vector<int64_t> round_slot0(groups.size() + 1, 0);
+        std::vector<std::vector<int64_t>> cursor(pieces.size(), std::vector<int64_t>((size_t)NB, 0));
+        for (size_t g = 0; g < groups.size(); ++g) {
+            int64_t list_len[kXcd] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < NB; ++b) {
+                int64_t at = list_len[b % kXcd];
+                for (size_t t = groups[g].first; t < groups[g].second; ++t) {
+                    cursor[t][(size_t)b] = at;                // where piece t's segments of block b go: behind the earlier pieces'
+                    at += pieces[t].per_block[(size_t)b];
+                }
+                list_len[b % kXcd] = (at + 3) / 4 * 4;
+            }
+            const int64_t longest = *std::max_element(list_len, list_len + kXcd);
+            round_slot0[g + 1] = round_slot0[g] + longest * kXcd;
+            Round r;
+            const CutPiece& head = pieces[groups[g].first];
+            const CutPiece& tail = pieces[groups[g].second - 1];
+            r.seg_lo = head.base;
+            r.seg_hi = tail.base + (int64_t)tail.begin.size();
+            r.w_first = head.v0;
+            r.n_words = tail.v0 + (int)tail.per_word.size() - head.v0;
+            r.slot_lo = round_slot0[g];
+            r.slot_count = longest * kXcd;
+            r.ent_first = c->rounds.empty() ? 0 : c->rounds.back().ent_first + c->rounds.back().ent_blocks;
+            r.ent_blocks = blocks_of(r.n_words);
+            c->rounds.push_back(r);
+        }
+        std::vector<int32_t> order((size_t)round_slot0.back(), -1);
+        std::vector<size_t> group_of(pieces.size(), 0);
+        for (size_t g = 0; g < groups.size(); ++g)
+            for (size_t t = groups[g].first; t < groups[g].second; ++t) group_of[t] = g;
+        run_on_threads(cut_threads, [&](int t) {
+            const CutPiece& piece = pieces[(size_t)t];
+            std::vector<int64_t>& cur = cursor[(size_t)t];
+            const int64_t slot0 = round_slot0[group_of[(size_t)t]];
+            for (size_t k = 0; k < piece.block.size(); ++k) {
+                const int32_t b = piece.block[k];
+                const int64_t i = cur[(size_t)b]++;
+                order[(size_t)(slot0 + ((i / 4) * kXcd + b % kXcd) * 4 + i % 4)] = (int32_t)(piece.base + (int64_t)k);
+            }
+        });
         c->exec_slots = (int64_t)order.size();
         A(dev_alloc(ctx, &c->d_exec_order, order.size()));
         if (rc != PYLDA_OK) return rc;
         if (hipMemcpy(c->d_exec_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
             return fail(ctx, PYLDA_ERR_HIP, "postings: H2D copy failed");
+    } else {
+        c->rounds.push_back(Round{0, c->nseg, 0, V, 0, c->nseg, 0, blocks_of(V)});
     }
+    c->partial_rows = 0;
+    for (const Round& r : c->rounds) c->partial_rows = std::max(c->partial_rows, r.seg_hi - r.seg_lo);
+    c->ent_blocks = c->rounds.back().ent_first + c->rounds.back().ent_blocks;
+    timer.lap("XCD execution order");
     A(dev_alloc(ctx, &c->d_seg_begin, (size_t)c->nseg));
     A(dev_alloc(ctx, &c->d_seg_end, (size_t)c->nseg));
     A(dev_alloc(ctx, &c->d_word_seg_ptr, (size_t)V + 1));
-    A(dev_alloc(ctx, &c->d_partial, (size_t)c->nseg * ctx->ldk));
+    timer.lap("segment array allocations");
+    A(dev_alloc(ctx, &c->d_partial, (size_t)c->partial_rows * ctx->ldk));
+    dev_free(c->d_entropy_partial);
+    A(dev_alloc(ctx, &c->d_entropy_partial, (size_t)c->ent_blocks));
     if (rc != PYLDA_OK) return rc;
+    timer.lap("partial rows allocation");
     auto H2D = [&](void* dst, const void* src, size_t bytes) {
         if (rc == PYLDA_OK && bytes && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
             rc = fail(ctx, PYLDA_ERR_HIP, "postings: H2D copy failed");
@@ -855,6 +995,7 @@ int build_postings(pylda_corpus* c)
     H2D(c->d_seg_end, seg_end.data(), (size_t)c->nseg * sizeof(int64_t));
     H2D(c->d_word_seg_ptr, word_seg_ptr.data(), ((size_t)V + 1) * sizeof(int64_t));
     if (rc != PYLDA_OK) return rc;
+    timer.lap("segment arrays H2D");
     c->have_postings = true;
     undo.keep = true;
     return PYLDA_OK;
@@ -864,12 +1005,13 @@ int build_postings(pylda_corpus* c)
 #define PYLDA_GATHER_U 4        // rows in flight per wavefront (cfg 3, 24 blocks: 4 -> 1.62 ms, 8 -> 1.71, 16 -> 2.3: occupancy)
 #endif
 template <typename P>
-void launch_gather(pylda_ctx* ctx, pylda_corpus* c)
+void launch_gather(pylda_ctx* ctx, pylda_corpus* c, const pylda_corpus::Round& r)
 {
     const int ldk = ctx->ldk;
     const P* pos = static_cast<const P*>(c->d_post_pos);
     const dim3 grid((unsigned)((c->nseg + 3) / 4), (unsigned)((ldk + 63) / 64));
-    const dim3 g1((unsigned)(((c->d_exec_order ? c->exec_slots : c->nseg) + 3) / 4));
+    const int32_t* order = c->d_exec_order ? c->d_exec_order + r.slot_lo : nullptr;
+    const dim3 g1((unsigned)((r.slot_count + 3) / 4));
 #define GATHER_ARGS c->d_seg_begin, c->d_seg_end, c->nseg, c->d_post_doc, pos, c->d_tfinal, c->d_rfinal
     if (ldk == 16)
         hipLaunchKernelGGL((sstats_gather_kernel<16, P>), grid, dim3(256), 0, ctx->stream, GATHER_ARGS, ldk, c->d_partial);
@@ -877,15 +1019,15 @@ void launch_gather(pylda_ctx* ctx, pylda_corpus* c)
         hipLaunchKernelGGL((sstats_gather_kernel<32, P>), grid, dim3(256), 0, ctx->stream, GATHER_ARGS, ldk, c->d_partial);
     else if (ctx->gather_rows && (ldk == 64 || ldk == 128 || ldk == 256)) {
         if (ldk == 128 && ctx->gather_rows == 2)
-            hipLaunchKernelGGL((sstats_gather_bulk_kernel<2, PYLDA_GATHER_U, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, c->d_exec_order);
+            hipLaunchKernelGGL((sstats_gather_bulk_kernel<2, PYLDA_GATHER_U, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, order, r.seg_lo);
         else if (ldk == 256 && ctx->gather_rows == 2)
-            hipLaunchKernelGGL((sstats_gather_bulk_kernel<4, PYLDA_GATHER_U, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, c->d_exec_order);
+            hipLaunchKernelGGL((sstats_gather_bulk_kernel<4, PYLDA_GATHER_U, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, order, r.seg_lo);
         else if (ldk == 64)
-            hipLaunchKernelGGL((sstats_gather_rows_kernel<1, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, c->d_exec_order);
+            hipLaunchKernelGGL((sstats_gather_rows_kernel<1, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, order, r.seg_lo);
         else if (ldk == 128)
-            hipLaunchKernelGGL((sstats_gather_rows_kernel<2, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, c->d_exec_order);
+            hipLaunchKernelGGL((sstats_gather_rows_kernel<2, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, order, r.seg_lo);
         else
-            hipLaunchKernelGGL((sstats_gather_rows_kernel<4, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, c->d_exec_order);
+            hipLaunchKernelGGL((sstats_gather_rows_kernel<4, P>), g1, dim3(256), 0, ctx->stream, GATHER_ARGS, c->d_partial, order, r.seg_lo);
     } else
         hipLaunchKernelGGL((sstats_gather_kernel<64, P>), grid, dim3(256), 0, ctx->stream, GATHER_ARGS, ldk, c->d_partial);
 #undef GATHER_ARGS
@@ -894,17 +1036,18 @@ void launch_gather(pylda_ctx* ctx, pylda_corpus* c)
 int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
 {
     const int ldk = ctx->ldk;
-    if (c->nseg > 0) {
-        if (c->wide_pos) launch_gather<int64_t>(ctx, c);
-        else launch_gather<int32_t>(ctx, c);
+    for (const pylda_corpus::Round& r : c->rounds) {
+        if (r.seg_hi > r.seg_lo) {
+            if (c->wide_pos) launch_gather<int64_t>(ctx, c, r);
+            else launch_gather<int32_t>(ctx, c, r);
+        }
+        if (r.ent_blocks > 0)
+            hipLaunchKernelGGL(sstats_finalize_kernel, dim3((unsigned)r.ent_blocks), dim3(256), 0, ctx->stream,
+                               c->d_word_seg_ptr, c->d_partial, ctx->d_expElog, ctx->d_expElog_elog, r.w_first, r.n_words, ldk,
+                               r.seg_lo, ctx->d_sstats, c->d_entropy_partial + r.ent_first);
     }
-    const int64_t total = (int64_t)ctx->V * ldk;
-    const unsigned fblocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(sstats_finalize_kernel, dim3(fblocks), dim3(256), 0, ctx->stream,
-                       c->d_word_seg_ptr, c->d_partial, ctx->d_expElog, ctx->d_expElog_elog, ctx->V, ldk,
-                       ctx->d_sstats, c->d_entropy_partial);
     hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_entropy_partial,
-                       (int64_t)fblocks, c->d_scalars + 2);
+                       c->ent_blocks, c->d_scalars + 2);
     HIP_TRY(ctx, hipGetLastError());
     return PYLDA_OK;
 }
@@ -1109,6 +1252,8 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     } else if (!strcmp(name, "quilt_odd")) {
         ctx->quilt_odd = value != 0;
         ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "gather_round_mb")) {   // (takes effect for corpora whose postings are built afterwards)
+        ctx->gather_round_mb = (int)std::max<int64_t>(0, value);
     } else if (!strcmp(name, "slab_uber")) {
         ctx->slab_uber = value != 0;
     } else if (!strcmp(name, "wide_postings")) {     // (takes effect for corpora whose postings are built afterwards)
@@ -1137,6 +1282,7 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
     if (D < 0 || D > INT32_MAX || !doc_ptr)
         return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: D=%lld", (long long)D);
     if (doc_ptr[0] != 0) return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: doc_ptr[0] != 0");
+    PhaseTimer timer;
     int64_t max_terms = 0;
     for (int64_t d = 0; d < D; ++d) {
         const int64_t n = doc_ptr[d + 1] - doc_ptr[d];
@@ -1158,14 +1304,39 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
     if (nnz > 0 && (!term_id || !term_ct))
         return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: NULL term arrays");
     int64_t tokens = 0;
-    for (int64_t i = 0; i < nnz; ++i) {
-        if (term_id[i] < 0 || term_id[i] >= ctx->V)
-            return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: term id %d at %lld outside [0,%d)",
-                        term_id[i], (long long)i, ctx->V);
-        if (term_ct[i] < 1)
-            return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: count %d at %lld", term_ct[i], (long long)i);
-        tokens += term_ct[i];
+    {
+        // term ids in range, counts >= 1, token total: on all host threads (198 M pairs at cfg 4)
+        const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, nnz / 4000000 + 1}));
+        std::vector<int64_t> bad_at((size_t)nthreads, -1), part((size_t)nthreads, 0);
+        auto check = [&](int t) {
+            const int64_t from = nnz * t / nthreads, to = nnz * (t + 1) / nthreads;
+            const int V = ctx->V;
+            int64_t sum = 0;
+            for (int64_t i = from; i < to; ++i) {
+                if ((unsigned)term_id[i] >= (unsigned)V || term_ct[i] < 1) {
+                    bad_at[(size_t)t] = i;
+                    return;
+                }
+                sum += term_ct[i];
+            }
+            part[(size_t)t] = sum;
+        };
+        std::vector<std::thread> workers;
+        for (int t = 1; t < nthreads; ++t) workers.emplace_back(check, t);
+        check(0);
+        for (auto& w : workers) w.join();
+        for (int t = 0; t < nthreads; ++t) {
+            const int64_t i = bad_at[(size_t)t];
+            if (i >= 0) {
+                if (term_id[i] < 0 || term_id[i] >= ctx->V)
+                    return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: term id %d at %lld outside [0,%d)",
+                                term_id[i], (long long)i, ctx->V);
+                return fail(ctx, PYLDA_ERR_INVALID, "corpus_create: count %d at %lld", term_ct[i], (long long)i);
+            }
+            tokens += part[(size_t)t];
+        }
     }
+    timer.lap("corpus validation");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     pylda_corpus* c = new (std::nothrow) pylda_corpus;
     if (!c) return fail(ctx, PYLDA_ERR_OOM, "corpus_create: host allocation failed");
@@ -1177,14 +1348,23 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
 
     // schedule: longest documents first (stable => deterministic)
     std::vector<int32_t> order((size_t)D);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        return doc_ptr[a + 1] - doc_ptr[a] > doc_ptr[b + 1] - doc_ptr[b];
-    });
+    if (max_terms <= (int64_t)4 << 20) {
+        // counting sort by distinct-term count, descending, documents of equal length in corpus order
+        std::vector<int64_t> at((size_t)max_terms + 2, 0);
+        for (int64_t d = 0; d < D; ++d) at[(size_t)(max_terms - (doc_ptr[d + 1] - doc_ptr[d])) + 1] += 1;
+        for (int64_t n = 0; n <= max_terms; ++n) at[(size_t)n + 1] += at[(size_t)n];
+        for (int64_t d = 0; d < D; ++d) order[(size_t)at[(size_t)(max_terms - (doc_ptr[d + 1] - doc_ptr[d]))]++] = (int32_t)d;
+    } else {
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            return doc_ptr[a + 1] - doc_ptr[a] > doc_ptr[b + 1] - doc_ptr[b];
+        });
+    }
     c->h_terms_sorted.resize((size_t)D);
     for (int64_t i = 0; i < D; ++i)
         c->h_terms_sorted[i] = (int32_t)(doc_ptr[order[i] + 1] - doc_ptr[order[i]]);
     build_plan(c);
+    timer.lap("schedule (sort + launch plan)");
 
     const int K = ctx->K;
     int rc = PYLDA_OK;
@@ -1221,6 +1401,7 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
         pylda_corpus_destroy(c);
         return rc;
     }
+    timer.lap("allocations + corpus H2D");
     *out = c;
     return PYLDA_OK;
 }
@@ -1899,6 +2080,8 @@ int64_t pylda_corpus_layout(pylda_corpus* c, const char* name)
     if (!c || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "gather_blocks")) return c->have_postings ? c->gather_blocks : 0;
     if (!strcmp(name, "gather_segments")) return c->have_postings ? c->nseg : 0;
+    if (!strcmp(name, "gather_rounds")) return c->have_postings ? (int64_t)c->rounds.size() : 0;
+    if (!strcmp(name, "gather_partial_rows")) return c->have_postings ? c->partial_rows : 0;
     return fail(c->ctx, PYLDA_ERR_INVALID, "corpus_layout: unknown name '%s'", name);
 }
 

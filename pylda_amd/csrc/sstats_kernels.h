@@ -76,13 +76,14 @@ __global__ __launch_bounds__(256) void sstats_gather_rows_kernel(
     const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end, int64_t nseg,
     const int32_t* __restrict__ post_doc, const P* __restrict__ post_pos,
     const double* __restrict__ tfinal, const double* __restrict__ rfinal, double* __restrict__ partial,
-    const int32_t* __restrict__ exec_order)
+    const int32_t* __restrict__ exec_order, int64_t seg_lo)
 {
     constexpr int ldk = 64 * NCH;
     const int lane = threadIdx.x & (kWave - 1);
     int64_t seg = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave;
     if (exec_order) seg = exec_order[seg];          // (the grid covers the padded list exactly; -1: no segment)
     if (seg < 0 || seg >= nseg) return;
+    partial += (size_t)(seg - seg_lo) * ldk;        // seg_lo: first segment of this round (rounds share the partial rows)
     const int64_t b = seg_begin[seg], e = seg_end[seg];
     double acc0[NCH], acc1[NCH];
 #pragma unroll
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void sstats_gather_rows_kernel(
         for (int j = 0; j < NCH; ++j) acc0[j] = fma(r0, t0[64 * j], acc0[j]);
     }
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) partial[(size_t)seg * ldk + lane + 64 * j] = acc0[j] + acc1[j];
+    for (int j = 0; j < NCH; ++j) partial[lane + 64 * j] = acc0[j] + acc1[j];
 }
 
 // The same pass with the postings' metadata fetched in bulk.  The kernel above walks a segment two postings at a
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void sstats_gather_bulk_kernel(
     const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end, int64_t nseg,
     const int32_t* __restrict__ post_doc, const P* __restrict__ post_pos,
     const double* __restrict__ tfinal, const double* __restrict__ rfinal, double* __restrict__ partial,
-    const int32_t* __restrict__ exec_order)
+    const int32_t* __restrict__ exec_order, int64_t seg_lo)
 {
     static_assert(NCH == 2 || NCH == 4, "table stride 128 or 256");
     static_assert(64 % U == 0, "whole trips over a 64-posting chunk");
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void sstats_gather_bulk_kernel(
             s.x += acc[u][j].x;
             s.y += acc[u][j].y;
         }
-        reinterpret_cast<f64x2*>(partial + (size_t)seg * ldk)[lane + 64 * j] = s;
+        reinterpret_cast<f64x2*>(partial + (size_t)(seg - seg_lo) * ldk)[lane + 64 * j] = s;
     }
 }
 
@@ -173,16 +174,18 @@ __global__ __launch_bounds__(256) void sstats_gather_bulk_kernel(
 // = sum_{w,k} (B log B)[w][k] * acc[w][k]; one partial per workgroup, summed in order afterwards.
 __global__ __launch_bounds__(256) void sstats_finalize_kernel(
     const int64_t* __restrict__ word_seg_ptr, const double* __restrict__ partial,
-    const double* __restrict__ expElog, const double* __restrict__ expElog_elog, int V, int ldk,
-    double* __restrict__ sstats, double* __restrict__ entropy_partial)
+    const double* __restrict__ expElog, const double* __restrict__ expElog_elog, int w_first, int n_words, int ldk,
+    int64_t seg_lo, double* __restrict__ sstats, double* __restrict__ entropy_partial)
 {
+    // words w_first .. w_first + n_words - 1 (one ROUND of the gather: the partial rows hold the segments from seg_lo on)
     __shared__ double scratch[4];
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t local = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double ent = 0.0;
-    if (idx < (int64_t)V * ldk) {
-        const int w = (int)(idx / ldk), k = (int)(idx - (int64_t)w * ldk);
+    if (local < (int64_t)n_words * ldk) {
+        const int w = w_first + (int)(local / ldk), k = (int)(local % ldk);
+        const int64_t idx = (int64_t)w * ldk + k;
         double s = 0.0;
-        for (int64_t sg = word_seg_ptr[w]; sg < word_seg_ptr[w + 1]; ++sg) s += partial[(size_t)sg * ldk + k];
+        for (int64_t sg = word_seg_ptr[w]; sg < word_seg_ptr[w + 1]; ++sg) s += partial[(size_t)(sg - seg_lo) * ldk + k];
         sstats[idx] = expElog[idx] * s;
         ent = expElog_elog[idx] * s;
     }

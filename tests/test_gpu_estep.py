@@ -403,6 +403,36 @@ def test_document_blocked_statistics_gather(capi, ap_train, K, blocks, rows):
     assert out[blocks][1] == out[0][1]
 
 
+@pytest.mark.parametrize("K,blocks", [(128, 16), (256, 8), (100, 24)])
+def test_statistics_gather_in_rounds(capi, ap_train, K, blocks):
+    """A (term, document block) pair costs a partial row; beyond a budget the gather runs in rounds over term ranges
+    that reuse the rows (cfg 4: 45 GB in one go).  With a 1 MiB budget a small corpus takes several rounds: the
+    statistics and the corpus likelihood are bitwise those of the single round."""
+    g = ap_train
+    rng = np.random.default_rng(K + blocks)
+    ptr = g["doc_ptr"][:601]
+    tid, tct = g["term_id"][:ptr[-1]], g["term_ct"][:ptr[-1]]
+    eta = rng.gamma(100.0, 0.01, (K, 6806))
+    alpha = rng.uniform(0.05, 1.0, K)
+    got = {}
+    for budget in (0, 1):
+        ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_blocks", blocks)
+        ctx.set_option("gather_round_mb", budget)
+        corpus = ctx.corpus(ptr, tid, tct)
+        res = ctx.estep_host(corpus, alpha, eta)
+        rounds, rows = corpus.layout("gather_rounds"), corpus.layout("gather_partial_rows")
+        ctx.set_option("doc_values", 0)
+        ctx.estep(corpus)
+        got[budget] = (res["sstats"], ctx.estep_results(corpus)[0], rounds, rows, corpus.layout("gather_segments"))
+        corpus.close()
+        ctx.close()
+    assert got[0][2] == 1 and got[0][3] == got[0][4]
+    assert got[1][2] >= 3 and got[1][3] <= got[0][3] // 3, got[1][2:]      # (a round holds at least one of the cut's 8 pieces)
+    assert np.array_equal(got[0][0], got[1][0])
+    assert abs(got[0][1] - got[1][1]) <= 1e-13 * abs(got[0][1])          # (the entropy partials are cut differently)
+
+
 def test_runs_on_the_system_hip_runtime_without_torch():
     """The library does not need PyTorch: with PYLDA_HIP_RUNTIME=system the loader leaves torch's bundled HIP
     runtime alone, and a process that never imports torch runs the smoke E-step against the oracle."""
@@ -515,19 +545,24 @@ def test_error_reporting(capi):
     with pytest.raises(capi.PyldaError):
         capi.Context(0, 5)
     ctx.close()
-    # a document with more distinct terms than any kernel can hold is refused with a clear message
+    # documents of any length run (round 2 refused anything above ~5,700 distinct terms) ...
     big = capi.Context(8, 20000)
-    with pytest.raises(capi.PyldaError) as e:
-        big.corpus(np.array([0, 12000]), np.arange(12000, dtype=np.int32), np.ones(12000, np.int32))
-    assert e.value.status == -1 and "distinct terms" in str(e.value)
-    ok = big.corpus(np.array([0, 4000]), np.arange(4000, dtype=np.int32), np.ones(4000, np.int32))
     big.set_alpha(np.full(8, 0.2))
     big.set_eta(np.random.default_rng(0).gamma(100.0, 0.01, (8, 20000)))
-    big.estep(ok)                                           # 4000 distinct terms: generic global-tile kernel
-    ll, _, _ = big.estep_results(ok)
-    assert np.isfinite(ll) and abs(big.get_sstats().sum() - 4000) < 1e-8
-    ok.close()
+    for n, kernel in ((4000, "generic_global"), (12000, "generic_huge")):
+        ok = big.corpus(np.array([0, n]), np.arange(n, dtype=np.int32), np.ones(n, np.int32))
+        assert [c["kernel"] for c in ok.plan()] == [kernel]
+        big.estep(ok)
+        ll, _, _ = big.estep_results(ok)
+        assert np.isfinite(ll) and abs(big.get_sstats().sum() - n) < 1e-8
+        ok.close()
     big.close()
+    # ... what is refused, with a clear message, is a K whose K-sized per-document arrays exceed the LDS
+    wide = capi.Context(6000, 4)
+    with pytest.raises(capi.PyldaError) as e:
+        wide.corpus(np.array([0, 1]), np.array([1], np.int32), np.array([2], np.int32))
+    assert e.value.status == -1 and "LDS" in str(e.value)
+    wide.close()
 
 
 def test_randomised_parity_sweep(capi):
