@@ -49,8 +49,8 @@ typedef enum pylda_status {
  *      pylda_set_stream(NULL) = HIP's null stream (pylda_use_own_stream restores the private one)
  *   3  additions only: pylda_abi_version, pylda_mstep_enqueue / pylda_outer_device / pylda_allreduce_outer /
  *      pylda_outer_fetch (one host wait per outer iteration), pylda_model_checkpoint, pylda_mark_time /
- *      pylda_elapsed_ms, pylda_work_counters, pylda_host_alloc / pylda_host_free; pylda_set_alpha no longer waits
- *      for the stream
+ *      pylda_elapsed_ms, pylda_work_counters, pylda_host_alloc / pylda_host_free, pylda_test_alpha_update;
+ *      pylda_set_alpha no longer waits for the stream (and is a no-op when handed the values the device holds)
  * A host compiled against another version must refuse to run: compare PYLDA_ABI_VERSION with
  * pylda_abi_version() right after loading the library. */
 #define PYLDA_ABI_VERSION 3
@@ -183,17 +183,25 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* corpus, const double* beta_v,
  *   pylda_mstep_enqueue   the device half of m_step (:218-235) - topic log-likelihood terms of the PRE-update eta,
  *                         eta <- sstats + beta, alpha sufficient statistics from the gamma of `corpus` - plus a
  *                         pack of every value the host half needs into one device vector; nothing is waited for;
- *   pylda_outer_device    that vector (2K + 4 doubles) and how many of its LEADING elements are rank-local sums:
+ *                         hyper_parameter_iteration > 0 also asks for the alpha update of the iteration
+ *                         (optimize_hyperparameters, :277-324, the reference's defaults: 100, 0.9, 10, 1e-6) ON THE
+ *                         DEVICE - it runs inside pylda_outer_fetch, behind the sum over the ranks, and leaves the new
+ *                         alpha where the next E-step reads it; 0: alpha stays (hyper_parameter_optimize_interval);
+ *   pylda_outer_device    that vector (3K + 4 doubles) and how many of its LEADING elements are rank-local sums:
  *                         [document log-likelihood (:214), #documents, documents redone in log space, 0,
- *                          alpha sufficient statistics (K) (:232-233) | per-topic likelihood terms (K), replicated];
+ *                          alpha sufficient statistics (K) (:232-233) | per-topic likelihood terms (K) | alpha (K),
+ *                          both replicated];
  *                         a multi-rank host sums the leading *n_reduce elements over the ranks in place, on the
  *                         context's stream (the Python class: torch.distributed; a C host: pylda_allreduce_outer);
- *   pylda_outer_fetch     one device-to-host copy + the wait; any output pointer may be NULL. */
-int pylda_mstep_enqueue(pylda_ctx* ctx, pylda_corpus* corpus, const double* beta_v);
+ *   pylda_outer_fetch     [the alpha update] + one device-to-host copy + the wait; any output pointer may be NULL;
+ *                         alpha_k receives the alpha the device now holds (updated or not). */
+int pylda_mstep_enqueue(pylda_ctx* ctx, pylda_corpus* corpus, const double* beta_v, int hyper_parameter_iteration,
+                        double hyper_parameter_decay_factor, int hyper_parameter_maximum_decay,
+                        double hyper_parameter_converge_threshold);
 void* pylda_outer_device(pylda_ctx* ctx, int64_t* n_reduce);
 int pylda_allreduce_outer(pylda_ctx* ctx);
 int pylda_outer_fetch(pylda_ctx* ctx, double* document_log_likelihood, double* number_of_documents,
-                      int64_t* logspace_documents, double* topic_log_likelihood, double* alpha_ss_k);
+                      int64_t* logspace_documents, double* topic_log_likelihood, double* alpha_ss_k, double* alpha_k);
 
 /* Page-locked host memory for the arrays of the public e_step() / m_step() contract (eta, the sufficient
  * statistics and gamma as host ndarrays, variational_bayes.py:212-216): buffers from here move at the PCIe rate
@@ -294,6 +302,13 @@ int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digam
 int pylda_parse_corpus(const char* text, int64_t text_bytes, int doc_separator, const char* vocab,
                        int64_t vocab_bytes, int lowercase, int64_t* n_docs, int64_t* nnz,
                        int64_t* doc_ptr, int32_t* term_id, int32_t* term_ct, int64_t* dropped_docs);
+
+/* Test hook: the device alpha update (optimize_hyperparameters, variational_bayes.py:277-324) on host vectors:
+ * alpha_k, alpha_ss_k (K each), #documents -> alpha_out_k. */
+int pylda_test_alpha_update(pylda_ctx* ctx, const double* alpha_k, const double* alpha_ss_k, double number_of_documents,
+                            int hyper_parameter_iteration, double hyper_parameter_decay_factor,
+                            int hyper_parameter_maximum_decay, double hyper_parameter_converge_threshold,
+                            double* alpha_out_k);
 
 /* Test hook: out[i] = exp(digamma(x[i]) - c), the fused form the inner loop uses. */
 int pylda_test_expdigamma(pylda_ctx* ctx, int64_t n, const double* x, double c, double* out);

@@ -56,10 +56,12 @@ SIGNATURES = {
     "pylda_allreduce_sstats": (ctypes.c_int, [_vp]),
     "pylda_allreduce_doubles": (ctypes.c_int, [_vp, _c_double_p, ctypes.c_int64]),
     "pylda_mstep": (ctypes.c_int, [_vp, _vp, _c_double_p, _c_double_p, _c_double_p]),
-    "pylda_mstep_enqueue": (ctypes.c_int, [_vp, _vp, _c_double_p]),
+    "pylda_mstep_enqueue": (ctypes.c_int, [_vp, _vp, _c_double_p, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                           ctypes.c_double]),
     "pylda_outer_device": (_vp, [_vp, _c_int64_p]),
     "pylda_allreduce_outer": (ctypes.c_int, [_vp]),
-    "pylda_outer_fetch": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_int64_p, _c_double_p, _c_double_p]),
+    "pylda_outer_fetch": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_int64_p, _c_double_p, _c_double_p,
+                                         _c_double_p]),
     "pylda_host_alloc": (ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(_vp)]),
     "pylda_host_free": (ctypes.c_int, [_vp]),
     "pylda_model_checkpoint": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -75,6 +77,8 @@ SIGNATURES = {
     "pylda_parse_corpus": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int, ctypes.c_char_p,
                                           ctypes.c_int64, ctypes.c_int, _c_int64_p, _c_int64_p, _c_int64_p,
                                           _c_int32_p, _c_int32_p, _c_int64_p]),
+    "pylda_test_alpha_update": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                               ctypes.c_int, ctypes.c_double, _c_double_p]),
     "pylda_test_expdigamma": (ctypes.c_int, [_vp, ctypes.c_int64, _c_double_p, ctypes.c_double, _c_double_p]),
     "pylda_test_special": (ctypes.c_int, [_vp, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p]),
 }
@@ -371,28 +375,33 @@ class Context(object):
                                           _dp(beta), ctypes.byref(tll), _dp(ass)))
         return tll.value, ass
 
-    def mstep_enqueue(self, corpus, beta):
-        """The device half of m_step, nothing waited for (see outer_fetch)."""
+    def mstep_enqueue(self, corpus, beta, hyper_parameter_iteration=0, hyper_parameter_decay_factor=0.9,
+                      hyper_parameter_maximum_decay=10, hyper_parameter_converge_threshold=1e-6):
+        """The device half of m_step, nothing waited for (see outer_fetch); hyper_parameter_iteration > 0 also
+        schedules the alpha update (optimize_hyperparameters) on the device."""
         beta = _f64(beta, (self.V,), "beta")
-        self._check(self._lib.pylda_mstep_enqueue(self._h, corpus._h, _dp(beta)))
+        self._check(self._lib.pylda_mstep_enqueue(self._h, corpus._h, _dp(beta), int(hyper_parameter_iteration),
+                                                  float(hyper_parameter_decay_factor), int(hyper_parameter_maximum_decay),
+                                                  float(hyper_parameter_converge_threshold)))
 
     def outer_device(self):
         """(device pointer, elements, leading elements that are rank-local sums) of the packed outer-iteration values."""
         n = ctypes.c_int64(0)
         ptr = self._lib.pylda_outer_device(self._h, ctypes.byref(n))
-        return int(ptr or 0), 2 * self.K + 4, int(n.value)
+        return int(ptr or 0), 3 * self.K + 4, int(n.value)
 
     def allreduce_outer(self):
         self._check(self._lib.pylda_allreduce_outer(self._h))
 
     def outer_fetch(self):
-        """(document_log_likelihood, number_of_documents, logspace_documents, topic_log_likelihood, alpha_ss):
-        the one host wait of an outer iteration."""
+        """(document_log_likelihood, number_of_documents, logspace_documents, topic_log_likelihood, alpha_ss,
+        alpha): the one host wait of an outer iteration; alpha is what the device holds now (updated there when
+        mstep_enqueue asked for it)."""
         ll, nd, tll, nlog = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
-        ass = np.empty(self.K, dtype=np.float64)
+        ass, alpha = np.empty(self.K, dtype=np.float64), np.empty(self.K, dtype=np.float64)
         self._check(self._lib.pylda_outer_fetch(self._h, ctypes.byref(ll), ctypes.byref(nd), ctypes.byref(nlog),
-                                                ctypes.byref(tll), _dp(ass)))
-        return ll.value, int(round(nd.value)), nlog.value, tll.value, ass
+                                                ctypes.byref(tll), _dp(ass), _dp(alpha)))
+        return ll.value, int(round(nd.value)), nlog.value, tll.value, ass, alpha
 
     def model_checkpoint(self, restore=False):
         self._check(self._lib.pylda_model_checkpoint(self._h, 1 if restore else 0))
@@ -450,6 +459,15 @@ class Context(object):
         ms, ss, calls = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
         self._check(self._lib.pylda_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(ss), ctypes.byref(calls)))
         return ms.value, ss.value, calls.value
+
+    def test_alpha_update(self, alpha, alpha_ss, number_of_documents, iterations=100, decay_factor=0.9, maximum_decay=10,
+                          threshold=1e-6):
+        alpha, alpha_ss = _f64(alpha, (self.K,), "alpha"), _f64(alpha_ss, (self.K,), "alpha_ss")
+        out = np.empty(self.K, dtype=np.float64)
+        self._check(self._lib.pylda_test_alpha_update(self._h, _dp(alpha), _dp(alpha_ss), float(number_of_documents),
+                                                      int(iterations), float(decay_factor), int(maximum_decay),
+                                                      float(threshold), _dp(out)))
+        return out
 
     def test_expdigamma(self, x, c):
         x = _f64(x)

@@ -115,7 +115,9 @@ struct pylda_ctx {
     int alpha_slot = 0;
     double* d_outer = nullptr;      // [doc ll, #documents, log-space documents, 0, alpha ss (K) | per-topic ll (K)]
     bool outer_ready = false;
-    bool outer_has_alpha_ss = false;
+    bool newton_pending = false;    // pylda_mstep_enqueue asked for the alpha update: pylda_outer_fetch runs it
+    NewtonParams newton;
+    double* d_newton_work = nullptr;   // 4 K
     double* d_eta_ckpt = nullptr;   // pylda_model_checkpoint
     double* d_work = nullptr;       // profiling: [sum_d I_d, sum_d I_d N_d] accumulated over E-steps
     hipEvent_t mark_event[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1166,10 +1168,11 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     CREATE_TRY(dev_alloc(ctx, &ctx->d_alpha, (size_t)K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_small, (size_t)(4 * K + 16)));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_partial, (size_t)1024 * K));
-    CREATE_TRY(dev_alloc(ctx, &ctx->d_outer, (size_t)(2 * K + 8)));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_outer, (size_t)(3 * K + 8)));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_newton_work, (size_t)4 * K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_work, (size_t)2));
     CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_work, 0, 2 * sizeof(double), ctx->stream), "hipMemsetAsync"));
-    CREATE_TRY(hip_ok(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), (size_t)(4 * K + 8) * sizeof(double), hipHostMallocDefault),
+    CREATE_TRY(hip_ok(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), (size_t)(5 * K + 8) * sizeof(double), hipHostMallocDefault),
                       "hipHostMalloc"));
     for (int i = 0; i < 2; ++i)
         CREATE_TRY(hip_ok(hipEventCreateWithFlags(&ctx->alpha_event[i], hipEventDisableTiming), "hipEventCreate"));
@@ -1192,7 +1195,7 @@ void pylda_destroy(pylda_ctx* ctx)
     dev_free(ctx->d_eta); dev_free(ctx->d_elog); dev_free(ctx->d_expElog); dev_free(ctx->d_expElog_elog); dev_free(ctx->d_sstats);
     dev_free(ctx->d_kv_scratch); dev_free(ctx->d_shift); dev_free(ctx->d_beta);
     dev_free(ctx->d_psi_rowsum); dev_free(ctx->d_topic_lse); dev_free(ctx->d_alpha);
-    dev_free(ctx->d_small); dev_free(ctx->d_partial); dev_free(ctx->d_outer); dev_free(ctx->d_work); dev_free(ctx->d_eta_ckpt);
+    dev_free(ctx->d_small); dev_free(ctx->d_partial); dev_free(ctx->d_outer); dev_free(ctx->d_newton_work); dev_free(ctx->d_work); dev_free(ctx->d_eta_ckpt);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (int i = 0; i < 2; ++i)
         if (ctx->alpha_event[i]) (void)hipEventDestroy(ctx->alpha_event[i]);
@@ -1465,6 +1468,11 @@ int pylda_set_alpha(pylda_ctx* ctx, const double* alpha_k)
     for (int k = 0; k < ctx->K; ++k)
         if (!(alpha_k[k] > 0.0) || !std::isfinite(alpha_k[k]))
             return fail(ctx, PYLDA_ERR_INVALID, "set_alpha: alpha[%d]=%g is not positive", k, alpha_k[k]);
+    // (the device already holds exactly these values: after an alpha update on the device - pylda_outer_fetch - the
+    //  host hands back what it was handed)
+    if (ctx->have_alpha && ctx->h_alpha.size() == (size_t)ctx->K &&
+        memcmp(ctx->h_alpha.data(), alpha_k, (size_t)ctx->K * sizeof(double)) == 0)
+        return PYLDA_OK;
     ctx->h_alpha.assign(alpha_k, alpha_k + ctx->K);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // no stream wait: the values go through one of two pinned slots (the copy is ordered on the stream behind the
@@ -1861,16 +1869,28 @@ int pylda_mstep(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, double* t
     return PYLDA_OK;
 }
 
-int pylda_mstep_enqueue(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v)
+int pylda_mstep_enqueue(pylda_ctx* ctx, pylda_corpus* c, const double* beta_v, int hyper_parameter_iteration,
+                        double hyper_parameter_decay_factor, int hyper_parameter_maximum_decay,
+                        double hyper_parameter_converge_threshold)
 {
     if (!ctx) return PYLDA_ERR_INVALID;
     if (!c || c->ctx != ctx || !c->estep_done || c->last_heldout)
         return fail(ctx, PYLDA_ERR_STATE, "mstep_enqueue: needs the corpus of the last training-mode E-step");
+    if (hyper_parameter_iteration < 0 || hyper_parameter_maximum_decay < 0 || hyper_parameter_maximum_decay > 16)
+        return fail(ctx, PYLDA_ERR_INVALID, "mstep_enqueue: hyper_parameter_iteration=%d, hyper_parameter_maximum_decay=%d (0..16)",
+                    hyper_parameter_iteration, hyper_parameter_maximum_decay);
+    ctx->newton_pending = hyper_parameter_iteration > 0;
+    if (ctx->newton_pending) {
+        ctx->newton.iterations = hyper_parameter_iteration;
+        ctx->newton.maximum_decay = hyper_parameter_maximum_decay;
+        ctx->newton.threshold = hyper_parameter_converge_threshold;
+        for (int d = 0; d <= 16; ++d) ctx->newton.decay_power[d] = std::pow(hyper_parameter_decay_factor, (double)d);   // numpy.power
+    }
     const int rc = enqueue_mstep(ctx, c, beta_v, true, "mstep_enqueue");
     if (rc != PYLDA_OK) return rc;
     const int K = ctx->K;
     hipLaunchKernelGGL(outer_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, c->d_scalars, c->d_flag_count,
-                       c->last_doc_values ? 1 : 0, (double)c->D, ctx->d_small + K, ctx->d_small, K, ctx->d_outer);
+                       c->last_doc_values ? 1 : 0, (double)c->D, ctx->d_small + K, ctx->d_small, ctx->d_alpha, K, ctx->d_outer);
     HIP_TRY(ctx, hipGetLastError());
     ctx->outer_ready = true;
     return PYLDA_OK;
@@ -1895,16 +1915,25 @@ int pylda_allreduce_outer(pylda_ctx* ctx)
 }
 
 int pylda_outer_fetch(pylda_ctx* ctx, double* document_log_likelihood, double* number_of_documents,
-                      int64_t* logspace_documents, double* topic_log_likelihood, double* alpha_ss_k)
+                      int64_t* logspace_documents, double* topic_log_likelihood, double* alpha_ss_k, double* alpha_k)
 {
     if (!ctx) return PYLDA_ERR_INVALID;
     if (!ctx->outer_ready) return fail(ctx, PYLDA_ERR_STATE, "outer_fetch: pylda_mstep_enqueue has not run");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int K = ctx->K;
+    if (ctx->newton_pending) {
+        // behind the all-reduce of the packed values (the statistics and #documents are the global ones on every rank)
+        hipLaunchKernelGGL(alpha_newton_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_outer + 4 + 2 * (size_t)K,
+                           ctx->d_outer + 4, ctx->d_outer + 1, K, ctx->newton, ctx->d_newton_work, ctx->d_alpha);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     double* host = ctx->h_pin + (size_t)2 * K;
-    HIP_TRY(ctx, hipMemcpyAsync(host, ctx->d_outer, (size_t)(2 * K + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(host, ctx->d_outer, (size_t)(3 * K + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the ONE wait of an outer iteration
     ctx->outer_ready = false;
+    if (ctx->newton_pending) ctx->h_alpha.assign(host + 4 + 2 * (size_t)K, host + 4 + 3 * (size_t)K);   // what d_alpha holds now
+    ctx->newton_pending = false;
+    if (alpha_k) memcpy(alpha_k, host + 4 + 2 * (size_t)K, (size_t)K * sizeof(double));
     if (document_log_likelihood) *document_log_likelihood = host[0];
     if (number_of_documents) *number_of_documents = host[1];
     if (logspace_documents) *logspace_documents = (int64_t)std::llround(host[2]);
@@ -2151,6 +2180,38 @@ int pylda_test_special(pylda_ctx* ctx, int64_t n, const double* x, double* digam
     }
     dev_free(dx); dev_free(dd); dev_free(dl);
     return rc;
+}
+
+int pylda_test_alpha_update(pylda_ctx* ctx, const double* alpha_k, const double* alpha_ss_k, double number_of_documents,
+                            int hyper_parameter_iteration, double hyper_parameter_decay_factor, int hyper_parameter_maximum_decay,
+                            double hyper_parameter_converge_threshold, double* alpha_out_k)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (!alpha_k || !alpha_ss_k || !alpha_out_k || hyper_parameter_iteration < 1 || hyper_parameter_maximum_decay < 0 ||
+        hyper_parameter_maximum_decay > 16)
+        return fail(ctx, PYLDA_ERR_INVALID, "test_alpha_update: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int K = ctx->K;
+    double* d = nullptr;                       // [alpha io (K) | statistics (K) | #documents | scratch alpha out (K)]
+    int rc = dev_alloc(ctx, &d, (size_t)3 * K + 1);
+    if (rc != PYLDA_OK) return rc;
+    NewtonParams np;
+    np.iterations = hyper_parameter_iteration;
+    np.maximum_decay = hyper_parameter_maximum_decay;
+    np.threshold = hyper_parameter_converge_threshold;
+    for (int i = 0; i <= 16; ++i) np.decay_power[i] = std::pow(hyper_parameter_decay_factor, (double)i);
+    hipError_t e = hipMemcpy(d, alpha_k, (size_t)K * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + K, alpha_ss_k, (size_t)K * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 2 * (size_t)K, &number_of_documents, sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(alpha_newton_kernel, dim3(1), dim3(1024), 0, ctx->stream, d, d + K, d + 2 * (size_t)K, K, np,
+                           ctx->d_newton_work, d + 2 * (size_t)K + 1);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(alpha_out_k, d, (size_t)K * sizeof(double), hipMemcpyDeviceToHost);
+    dev_free(d);
+    if (e != hipSuccess) return fail(ctx, PYLDA_ERR_HIP, "test_alpha_update: %s", hipGetErrorString(e));
+    return PYLDA_OK;
 }
 
 int pylda_test_expdigamma(pylda_ctx* ctx, int64_t n, const double* x, double c, double* out)

@@ -63,6 +63,27 @@ __device__ __forceinline__ double digamma(double x)
     return digamma_asymptotic(x + 10.0) - shift;
 }
 
+// psi'(x) (scipy.special.polygamma(1, x)), x > 0: recurrence psi'(x) = psi'(x + 1) + 1 / x^2 up to x >= 12, then
+//   psi'(y) = 1/y + 1/(2 y^2) + sum_n B_2n / y^(2n+1)        (truncation < 2e-18 relative at y = 12)
+// Only the alpha update (mstep_kernels.h, K evaluations per Newton iteration) uses it: plain divisions.
+__device__ __forceinline__ double trigamma(double x)
+{
+    double shift = 0.0;
+    while (x < 12.0) {
+        shift += 1.0 / (x * x);
+        x += 1.0;
+    }
+    const double inv = 1.0 / x, w = inv * inv;
+    double s = 7.0 / 6.0;                         // B_14
+    s = fma(s, w, -691.0 / 2730.0);               // B_12
+    s = fma(s, w, 5.0 / 66.0);                    // B_10
+    s = fma(s, w, -1.0 / 30.0);                   // B_8
+    s = fma(s, w, 1.0 / 42.0);                    // B_6
+    s = fma(s, w, -1.0 / 30.0);                   // B_4
+    s = fma(s, w, 1.0 / 6.0);                     // B_2
+    return shift + (inv + 0.5 * w + s * w * inv);
+}
+
 // exp(x) for |x| < 700, Estrin-evaluated degree-13 Taylor polynomial on the
 // reduced argument |r| <= ln2/2 (truncation 4e-18): 1-2 ulp, dependency depth 9.
 __device__ __forceinline__ double exp_shallow(double x)

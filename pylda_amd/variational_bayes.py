@@ -281,18 +281,25 @@ class VariationalBayes(Inferencer):
         self._gamma_host_stale = self._gamma_on_device = True
         if timed:
             ctx.mark_time(1)
-        ctx.mstep_enqueue(corpus, self._alpha_beta)
+        update_alpha = self._hyper_parameter_optimize_interval > 0 and \
+            self._counter % self._hyper_parameter_optimize_interval == 0
+        # the alpha update (optimize_hyperparameters, :277-324, with the reference's defaults) runs on the device
+        # behind the sum over the ranks, unless a subclass replaced the method or _device_alpha_update is cleared
+        on_device = update_alpha and self.__dict__.get("_device_alpha_update", True) and \
+            type(self).optimize_hyperparameters is VariationalBayes.optimize_hyperparameters
+        ctx.mstep_enqueue(corpus, self._alpha_beta, hyper_parameter_iteration=100 if on_device else 0)
         if group is not None:
             distributed.allreduce_outer(ctx, group)
         if timed:
             ctx.mark_time(2)
-        document_log_likelihood, number_of_documents, _, topic_log_likelihood, alpha_sufficient_statistics = \
+        document_log_likelihood, number_of_documents, _, topic_log_likelihood, alpha_sufficient_statistics, alpha = \
             ctx.outer_fetch()
         self._eta_device_newer = True
         clock_e_step = ctx.elapsed_ms(0, 1) * 1e-3 if timed else 0.0
         clock_m_step = time.time()
-        if self._hyper_parameter_optimize_interval > 0 and \
-                self._counter % self._hyper_parameter_optimize_interval == 0:
+        if on_device:
+            self._alpha_alpha = alpha
+        elif update_alpha:
             self.optimize_hyperparameters(alpha_sufficient_statistics,
                                           number_of_documents=number_of_documents)
         clock_m_step = time.time() - clock_m_step + (ctx.elapsed_ms(1, 2) * 1e-3 if timed else 0.0)

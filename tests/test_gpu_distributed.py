@@ -193,7 +193,7 @@ def _c_abi_two_rank_worker(rank, world, uid_path, out_dir):
     ctx.allreduce_sstats()
     ctx.mstep_enqueue(corpus, g["beta"])
     ctx.allreduce_outer()
-    ll, nd, _, tll, ass = ctx.outer_fetch()
+    ll, nd, _, tll, ass, _ = ctx.outer_fetch()
     np.savez(os.path.join(out_dir, "c%d.npz" % rank), ll=ll, nd=nd, tll=tll, ass=ass, eta=ctx.get_eta())
     ctx.comm_destroy()
     corpus.close()
@@ -215,7 +215,7 @@ def test_two_gpus_through_the_c_abi_communicator(ap_train, tmp_path):
     ctx.set_eta(g["eta"])
     ctx.estep(corpus)
     ctx.mstep_enqueue(corpus, g["beta"])
-    ll, nd, _, tll, ass = ctx.outer_fetch()
+    ll, nd, _, tll, ass, _ = ctx.outer_fetch()
     eta = ctx.get_eta()
     corpus.close()
     ctx.close()

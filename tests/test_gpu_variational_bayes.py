@@ -281,3 +281,31 @@ def test_reference_rng_stream_and_progress_lines(ap_train, capsys):
     assert after == np.random.random() and after != untouched
     assert capsys.readouterr().out.splitlines() == ["successfully processed 1000 documents...",
                                                     "successfully processed 2000 documents..."]
+
+
+@pytest.mark.parametrize("K,docs,seed", [(1, 50, 0), (10, 2000, 1), (128, 100000, 2), (500, 2235, 3), (1500, 300, 4), (10, 2000, 5)])
+def test_alpha_update_on_the_device(ap_train, K, docs, seed):
+    """learning()'s alpha update runs on the device (alpha_newton_kernel): the reference's Newton iteration with its
+    decaying step and its element-wise 1 / hessian (variational_bayes.py:277-324), against the numpy restatement that
+    is pinned to the reference's own update (tests/test_host_logic.py); seed 5 starts from an alpha whose first steps
+    are refused (the decay path), K = 10 / docs = 2000 with seed 1 is the associated-press golden itself."""
+    from oracle import vb_numpy
+    from pylda_amd import _capi
+    rng = np.random.default_rng(seed)
+    if seed == 1:
+        alpha, stats = ap_train["alpha"].copy(), ap_train["alpha_ss"].copy()
+    else:
+        alpha = rng.uniform(0.01, 2.0, K) if seed != 5 else np.full(K, 1e-3)
+        gamma = rng.gamma(0.3 if seed != 5 else 5.0, 1.0, (min(docs, 400), K)) + 1e-3
+        stats = np.sum(vb_numpy.compute_dirichlet_expectation(gamma), axis=0) * (docs / gamma.shape[0])
+    ctx = _capi.Context(K, 4)
+    got = ctx.test_alpha_update(alpha, stats, docs)
+    ctx.close()
+    with np.errstate(all="ignore"):
+        want = vb_numpy.optimize_hyperparameters(alpha, stats, docs)
+    if K == 1:      # the reference's vector c is sum_g_h / (1/z + 1/h) with h = -z at K = 1: 0/0, alpha becomes NaN - here too
+        assert np.isnan(want).all() and np.isnan(got).all()
+        return
+    assert np.all(got > 0) and rel_err(got, want) < 1e-10, (got[:4], want[:4])
+    if seed == 1:
+        assert rel_err(got, ap_train["alpha_after"]) < 1e-10
