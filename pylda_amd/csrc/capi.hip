@@ -618,7 +618,13 @@ int launch_qfuse_np(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 
 int launch_qfuse(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
-    return ctx->ldk == 512 ? launch_qfuse_np<4, 6, 2>(ctx, p, L) : launch_qfuse_np<3, 8, 3>(ctx, p, L);
+#ifndef PYLDA_QF4_RWL
+#define PYLDA_QF4_RWL 6
+#endif
+#ifndef PYLDA_QF4_TWL
+#define PYLDA_QF4_TWL 2
+#endif
+    return ctx->ldk == 512 ? launch_qfuse_np<4, PYLDA_QF4_RWL, PYLDA_QF4_TWL>(ctx, p, L) : launch_qfuse_np<3, 8, 2>(ctx, p, L);
 }
 
 template <int NP>

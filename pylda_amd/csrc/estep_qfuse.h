@@ -29,7 +29,10 @@
 
 namespace pylda {
 
-constexpr int kQfMaxSlots = 128;            // word slots per wavefront: documents up to 1024 distinct terms
+#ifndef PYLDA_QF_SLOTS
+#define PYLDA_QF_SLOTS 128
+#endif
+constexpr int kQfMaxSlots = PYLDA_QF_SLOTS;   // word slots per wavefront: documents up to 1024 distinct terms
 
 template <int NP, int TWL>
 struct QfuseLds {
@@ -107,12 +110,30 @@ __device__ __forceinline__ double lane_dot(const double (&row)[6], const double 
     return a + b;
 }
 
+// Sum over each 32-lane half of the wavefront, result in every lane of the half: wave_sum (estep_common.h) without
+// its last level - four DPP levels inside the 16-lane rows, one permlane16 swap across the two rows of a half.
+__device__ __forceinline__ double half_wave_sum(double v)
+{
+#define PYLDA_DPP_ADD(CTRL)                                                                     \
+    v += __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false),   \
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false))
+    PYLDA_DPP_ADD(0xB1);        // quad_perm [1,0,3,2]
+    PYLDA_DPP_ADD(0x4E);        // quad_perm [2,3,0,1]
+    PYLDA_DPP_ADD(0x141);       // row_half_mirror
+    PYLDA_DPP_ADD(0x140);       // row_mirror
+#undef PYLDA_DPP_ADD
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);       // rows 0+1 | 0+1 | 2+3 | 2+3
+}
+
 template <int NP, int RWL, int TWL>
 __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
 {
     using L = QfuseLds<NP, TWL>;
     constexpr int W = 8, NT = 512, KT = 128 * NP, KRL = 2 * NP;
     static_assert(NP == 3 || NP == 4, "table stride 384 or 512");
+    static_assert(RWL % 2 == 0 && TWL % 2 == 0, "words are processed in pairs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sp = reinterpret_cast<double*>(smem + L::sp);
     double* tt = reinterpret_cast<double*>(smem + L::tt);
@@ -205,32 +226,43 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
         double q[KRL];
 #pragma unroll
         for (int j = 0; j < KRL; ++j) q[j] = 0.0;
-        // one word, fused: normaliser (wavefront sum of the lanes' 8-topic dots), r, topic sums
-        auto word = [&](const double (&row)[KRL], int slot) {
-            const double cnt = mycnt[slot];
-            const double nrm = wave_sum(lane_dot(row, tq));
+        // TWO words (slots `slot`, `slot + 1`), fused: normalisers, r, topic sums.  A word costs ~20 instructions of
+        // wavefront reduction and reciprocal around its 2 x 8 FMAs, and this kernel is bound by exactly that issue
+        // count (on-chip capacity barely matters: 24 or 56 words on chip, 5.15 vs 4.97 ms at K = 500).  In pairs: one
+        // swap level folds the two words' per-lane dots into ONE register (word A's partial sums in lanes 0-31, B's in
+        // 32-63), so the five remaining reduction levels, the range check and the reciprocal run once for both.
+        auto word_pair = [&](const double (&rowA)[KRL], const double (&rowB)[KRL], int slot) {
+            const double nrm = half_wave_sum(swap32_add(lane_dot(rowA, tq), lane_dot(rowB, tq)));
+            const double cnt = mycnt[slot + (c >> 5)];
             const bool live = cnt > 0.0;
             if (live && !(nrm > 1e-280 && nrm < 1e300)) bad = 1;
             const double r = live ? cnt * rcp_newton(nrm) : 0.0;
-            if (c == 0) myrr[slot] = r;
+            if ((c & 31) == 0) myrr[slot + (c >> 5)] = r;
+            const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(r), __double2loint(r), false, false);
+            const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(r), __double2hiint(r), false, false);
+            const double rA = __hiloint2double(hi[0], lo[0]), rB = __hiloint2double(hi[1], lo[1]);   // every lane: r of A, of B
 #pragma unroll
-            for (int j = 0; j < KRL; ++j) q[j] = fma(r, row[j], q[j]);
+            for (int j = 0; j < KRL; ++j) q[j] = fma(rA, rowA[j], q[j]);
+#pragma unroll
+            for (int j = 0; j < KRL; ++j) q[j] = fma(rB, rowB[j], q[j]);
         };
 #pragma unroll
-        for (int i = 0; i < RWL; ++i) {
-            word(B[i], i);
-            if (i & 1) __builtin_amdgcn_sched_barrier(0);     // two words' chains side by side, not eight (registers)
+        for (int i = 0; i < RWL; i += 2) {
+            word_pair(B[i], B[i + 1], i);
+            __builtin_amdgcn_sched_barrier(0);                // one pair's chains at a time (registers)
         }
 #pragma unroll
-        for (int t = 0; t < TWL; ++t) {
-            double row[KRL];
+        for (int t = 0; t < TWL; t += 2) {
+            double rowA[KRL], rowB[KRL];
 #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
-                const double2 v2 = myrows[t * (KT / 2) + 64 * jj];
-                row[2 * jj] = v2.x;
-                row[2 * jj + 1] = v2.y;
+                const double2 v2 = myrows[t * (KT / 2) + 64 * jj], w2 = myrows[(t + 1) * (KT / 2) + 64 * jj];
+                rowA[2 * jj] = v2.x;
+                rowA[2 * jj + 1] = v2.y;
+                rowB[2 * jj] = w2.x;
+                rowB[2 * jj + 1] = w2.y;
             }
-            word(row, RWL + t);
+            word_pair(rowA, rowB, RWL + t);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (NS > 0) {
@@ -242,17 +274,16 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
             global_row_request(g2, row_address(kOnChip + 2));
             global_row_request(g3, row_address(kOnChip + 3));
             int s = kOnChip;
-            double row[KRL];
-            for (; s + 4 < Spad; s += 4) {          // full trips: every buffer is re-requested four slots ahead
-                global_row_wait<3>(g0); g0.unpack(row); word(row, s + 0); global_row_request(g0, row_address(s + 4)); __builtin_amdgcn_sched_barrier(0);
-                global_row_wait<3>(g1); g1.unpack(row); word(row, s + 1); global_row_request(g1, row_address(s + 5)); __builtin_amdgcn_sched_barrier(0);
-                global_row_wait<3>(g2); g2.unpack(row); word(row, s + 2); global_row_request(g2, row_address(s + 6)); __builtin_amdgcn_sched_barrier(0);
-                global_row_wait<3>(g3); g3.unpack(row); word(row, s + 3); global_row_request(g3, row_address(s + 7)); __builtin_amdgcn_sched_barrier(0);
+            double rowA[KRL], rowB[KRL];
+            for (; s + 4 < Spad; s += 4) {          // full trips: a pair of buffers is re-requested four slots ahead
+                global_row_wait<2>(g0); global_row_wait<2>(g1); g0.unpack(rowA); g1.unpack(rowB); word_pair(rowA, rowB, s + 0);
+                global_row_request(g0, row_address(s + 4)); global_row_request(g1, row_address(s + 5)); __builtin_amdgcn_sched_barrier(0);
+                global_row_wait<2>(g2); global_row_wait<2>(g3); g2.unpack(rowA); g3.unpack(rowB); word_pair(rowA, rowB, s + 2);
+                global_row_request(g2, row_address(s + 6)); global_row_request(g3, row_address(s + 7)); __builtin_amdgcn_sched_barrier(0);
             }
-            global_row_wait<3>(g0); g0.unpack(row); word(row, s + 0); __builtin_amdgcn_sched_barrier(0);    // last trip: the pipeline drains
-            global_row_wait<2>(g1); g1.unpack(row); word(row, s + 1); __builtin_amdgcn_sched_barrier(0);
-            global_row_wait<1>(g2); g2.unpack(row); word(row, s + 2); __builtin_amdgcn_sched_barrier(0);
-            global_row_wait<0>(g3); g3.unpack(row); word(row, s + 3);
+            global_row_wait<2>(g0); global_row_wait<2>(g1); g0.unpack(rowA); g1.unpack(rowB); word_pair(rowA, rowB, s + 0);   // last trip: the pipeline drains
+            __builtin_amdgcn_sched_barrier(0);
+            global_row_wait<0>(g2); global_row_wait<0>(g3); g2.unpack(rowA); g3.unpack(rowB); word_pair(rowA, rowB, s + 2);
         }
         // per-wavefront topic partials: lane c, register j  <->  topic 2c + 128*(j>>1) + (j&1)
 #pragma unroll

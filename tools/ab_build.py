@@ -3,12 +3,12 @@
 GPU box without touching the working tree's library):
 
     python tools/ab_build.py prio -DPYLDA_QUAD_CPRIO=3
-    gpurun -- 'cd .scratch/prio && python tools/class_ab.py cfg3 193 208'
+    gpurun -- 'cd .ab/prio && python tools/class_ab.py cfg3 193 208'
 """
 import os, shutil, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, flags = sys.argv[1], sys.argv[2:]
-dst = os.path.join(root, ".scratch", tag)
+dst = os.path.join(root, ".ab", tag)
 shutil.rmtree(dst, ignore_errors=True)
 os.makedirs(dst)
 for d in ("pylda_amd", "include", "tools"):
