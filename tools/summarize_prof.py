@@ -42,32 +42,45 @@ def main(root):
 
 def estep_traffic(root):
     """HBM bytes of one E-step (document kernels + statistics pass) from the FETCH_SIZE / WRITE_SIZE passes:
-    per-dispatch averages summed over the E-step's kernels, FETCH_SIZE doubled (gfx950 counts the 128-byte
-    requests of wide coalesced reads at 64 bytes: MI355X_MICROARCH.md, HBM)."""
+    the counters of ALL dispatches of the E-step's kernels divided by the number of E-steps in the pass (a kernel
+    may run several times per E-step: launch classes, rounds of the statistics gather), FETCH_SIZE doubled (gfx950
+    counts the 128-byte requests of wide coalesced reads at 64 bytes: MI355X_MICROARCH.md, HBM)."""
     import json
-    mine = ("estep_", "sstats_")
-    out = {}
+    import sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    mine = ("estep_", "sstats_", "doc_terms")
+    out, esteps = {}, {}
     for counter, sub in (("FETCH_SIZE", "pmc3"), ("WRITE_SIZE", "pmc4")):
-        acc, calls = defaultdict(float), defaultdict(set)
+        acc, once = defaultdict(float), set()
         for path in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(path)):
+                k = short(r["Kernel_Name"]).replace("void ", "")
+                if k.startswith("eta_rowsum_psi"):
+                    once.add(r["Dispatch_Id"])              # one per E-step (table preparation)
                 if r["Counter_Name"] != counter:
                     continue
-                k = short(r["Kernel_Name"]).replace("void ", "")
                 if k.startswith(mine) and "logspace" not in k:
                     acc[k] += float(r["Counter_Value"])
-                    calls[k].add(r["Dispatch_Id"])
-        out[counter] = {k: acc[k] / max(1, len(calls[k])) for k in acc}
+        n = max(1, len(once))
+        esteps[counter] = n
+        out[counter] = {k: acc[k] / n for k in acc}
     if not out["FETCH_SIZE"]:
         return
     fetch_kb = sum(out["FETCH_SIZE"].values())
     write_kb = sum(out["WRITE_SIZE"].values())
+    try:
+        from bench import kernel_source_hash
+        source_hash = kernel_source_hash()
+    except Exception:
+        source_hash = None
     doc = {"FETCH_SIZE_KB_per_kernel": out["FETCH_SIZE"], "WRITE_SIZE_KB_per_kernel": out["WRITE_SIZE"],
-           "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+           "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "esteps_in_pass": esteps,
+           "kernel_source_hash": source_hash,
            "correction": "FETCH_SIZE * 2 (gfx950: 128-byte requests of wide coalesced reads are tallied at 64 bytes, "
-                         "MI355X_MICROARCH.md HBM section); WRITE_SIZE as is; KB = 1024 bytes",
+                         "MI355X_MICROARCH.md HBM section); WRITE_SIZE as is; KB = 1024 bytes; per E-step = all dispatches "
+                         "of the E-step's kernels / E-steps in the pass",
            "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024)}
-    print("== E-step traffic (per launch):", json.dumps(doc))
+    print("== E-step traffic (per E-step):", json.dumps(doc))
     with open(os.path.join(root, "traffic.json"), "w") as fh:
         json.dump(doc, fh, indent=1)
 
