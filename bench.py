@@ -371,6 +371,7 @@ def measure(job, args, name, steps, warmup, docs=None):
                      "statistics_gather": {"document_blocks": vb._train_corpus.layout("gather_blocks"),
                                            "segments": vb._train_corpus.layout("gather_segments"),
                                            "rounds": vb._train_corpus.layout("gather_rounds"),
+                                           "sweep_passes": vb._train_corpus.layout("gather_sweep_passes"),
                                            "partial_row_bytes": vb._train_corpus.layout("gather_partial_rows") * 8 *
                                            ctx_table_stride(ctx)}},
         # the honest companion: the document kernels are fp64-VALU / latency bound, not HBM bound;

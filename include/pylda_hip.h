@@ -250,8 +250,8 @@ int pylda_corpus_plan(pylda_corpus* corpus, int32_t capacity, int32_t* variant, 
 /* Layout facts of an uploaded corpus (measurement / test hook): "gather_blocks" - document blocks of the
  * statistics gather (1: unblocked; set when the first training E-step builds the postings, 0 before),
  * "gather_segments" - its posting segments, "gather_rounds" - the term ranges the gather is run in so that their
- * segments share one set of partial rows, "gather_partial_rows" - those rows.  Returns the value, or a negative
- * pylda_status. */
+ * segments share one set of partial rows, "gather_partial_rows" - those rows, "gather_sweep_passes" - passes of the
+ * persistent sweep that replaces rows and rounds (0: not in use).  Returns the value, or a negative pylda_status. */
 int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
 
 /* Tuning / test options:
@@ -273,6 +273,10 @@ int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
  *   "gather_blocks"  document blocks of that gather, for corpora created afterwards: -1 (default)
  *                    automatic - blocks of about one L2 while a (term, block) pair keeps >= 8
  *                    postings, else unblocked; 0 / 1 off; n > 1 forced (a multiple of 8);
+ *   "gather_sweep"   the document-blocked gather as ONE persistent kernel in which every wavefront owns a few terms
+ *                    and all workgroups sweep the document blocks together (no partial rows; table stride 128 / 256):
+ *                    0 never, 1 (default) where the partial rows of the dispatch-paced gather would exceed their
+ *                    budget, 2 whenever the gather is blocked;
  *   "gather_round_mb" budget of the gather's partial rows (one per (term, document block) pair) in MiB, 0 = 4 GiB:
  *                    beyond it the gather runs in rounds over term ranges that reuse the rows;
  *   "wide_postings"  1: 64-bit CSR positions in the postings whatever the corpus size (automatic from 2^31 pairs);

@@ -37,6 +37,7 @@
 #include "postings.h"
 #include "prepare_kernels.h"
 #include "sstats_kernels.h"
+#include "sstats_sweep.h"
 
 using namespace pylda;
 
@@ -131,6 +132,9 @@ struct pylda_ctx {
     int quilt12 = 0;
     int gather_rows = 2;            // 0: 64-topic chunks; 1: whole rows (ldk 64 / 128 / 256); 2: + postings in bulk (ldk 128 / 256)
     int gather_blocks = -1;         // document blocks of the gather: -1 automatic, 0 / 1 off, n forced (multiple of 8)
+    int sweep_spin = 4000;          // polls of a rendezvous of the sweep before a workgroup goes on alone
+    int gather_sweep = 1;           // the persistent sweep (sstats_sweep.h) at stride 128 / 256: 0 never, 1 when the partial rows of the
+                                    // dispatch-paced gather would exceed their budget (rounds), 2 whenever the gather is blocked
     int gather_round_mb = 0;        // budget of the gather's partial rows per round, MiB (0: 4 GiB)
     int slab_uber = 1;              // small corpora: all slab launch classes in one dispatch
     int wide_postings = 0;          // test hook: 64-bit CSR positions in the postings whatever nnz (automatic from 2^31 pairs)
@@ -189,6 +193,12 @@ struct pylda_corpus {
     struct Round { int64_t seg_lo, seg_hi; int w_first, n_words; int64_t slot_lo, slot_count; int64_t ent_first, ent_blocks; };
     std::vector<Round> rounds;
     int64_t partial_rows = 0, ent_blocks = 0;
+    // ... or the persistent sweep (sstats_sweep.h): no partial rows at all
+    bool sweep = false;
+    int sweep_passes = 0, sweep_terms = 0, sweep_wpb = 0;   // passes over the document blocks, terms per wavefront, wavefronts per workgroup
+    int32_t* d_seg_block = nullptr;             // document block of every segment
+    int32_t* d_term_of = nullptr;               // [passes][wavefronts][terms per wavefront]
+    unsigned* d_rendezvous = nullptr;
     int gather_blocks = 1;
     int64_t* d_word_seg_ptr = nullptr;  // V+1
     double* d_partial = nullptr;   // nseg x ldk
@@ -745,6 +755,30 @@ int enqueue_prepare(pylda_ctx* ctx, bool heldout)
     return PYLDA_OK;
 }
 
+// Geometry of the persistent sweep (sstats_sweep.h) for V terms: terms per wavefront and wavefronts per workgroup (one
+// workgroup per CU) such that the fewest passes over the document blocks cover all terms.
+struct SweepGeom { int T, WPB, passes; };
+SweepGeom sweep_geom_for(const pylda_ctx* ctx, int V)
+{
+    const int64_t cus = ctx->num_cu;
+    auto passes = [&](int T, int WPB) { return (int)((V + cus * WPB * T - 1) / (cus * WPB * T)); };
+    if (ctx->ldk == 128) {
+        if (passes(12, 16) == 1) return {12, 16, 1};
+        return {16, 16, passes(16, 16)};
+    }
+    const int a = passes(8, 16), b = passes(12, 12);       // stride 256: 8 VGPRs per term
+    return b < a ? SweepGeom{12, 12, b} : SweepGeom{8, 16, a};
+}
+
+#define PYLDA_SWEEP_DISPATCH(ctx, c, DO)                                                             \
+    do {                                                                                             \
+        const int t_ = (c)->sweep_terms, w_ = (c)->sweep_wpb;                                        \
+        if ((ctx)->ldk == 128 && t_ == 12) { if ((c)->wide_pos) { DO(2, 12, 16, int64_t); } else { DO(2, 12, 16, int32_t); } } \
+        else if ((ctx)->ldk == 128) { if ((c)->wide_pos) { DO(2, 16, 16, int64_t); } else { DO(2, 16, 16, int32_t); } }       \
+        else if (w_ == 12) { if ((c)->wide_pos) { DO(4, 12, 12, int64_t); } else { DO(4, 12, 12, int32_t); } }                 \
+        else { if ((c)->wide_pos) { DO(4, 8, 16, int64_t); } else { DO(4, 8, 16, int32_t); } }                                \
+    } while (0)
+
 // One host thread's share of the segment cut (build_postings): the segments of a contiguous range of terms.
 struct CutPiece {
     std::vector<int64_t> begin, end, per_word;
@@ -784,6 +818,8 @@ int build_postings(pylda_corpus* c)
             if (c->d_post_pos) (void)hipFree(c->d_post_pos);
             c->d_post_pos = nullptr;
             dev_free(c->d_exec_order); dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial);
+            dev_free(c->d_seg_block); dev_free(c->d_term_of); dev_free(c->d_rendezvous);
+            c->sweep = false;
             c->nseg = 0;
             c->exec_slots = 0;
             c->rounds.clear();
@@ -835,6 +871,23 @@ int build_postings(pylda_corpus* c)
     using Round = pylda_corpus::Round;
     std::vector<CutPiece> pieces;
     int cut_threads = 1;
+    // the persistent sweep (sstats_sweep.h) instead of partial rows: its geometry must be resident, one workgroup per CU
+    bool want_sweep = false;
+    if (NB > 1 && nnz > 0 && ctx->gather_sweep && (ctx->ldk == 128 || ctx->ldk == 256) && ctx->gather_rows == 2) {
+        const SweepGeom g = sweep_geom_for(ctx, V);
+        c->sweep_terms = g.T;
+        c->sweep_wpb = g.WPB;
+        c->sweep_passes = g.passes;
+        // (mode 1: only where the (term, block) partial rows - about V x NB of them - would not fit their budget)
+        const double budget = ctx->gather_round_mb > 0 ? (double)ctx->gather_round_mb * 1048576.0 : 4.0 * 1073741824.0;
+        const double rows_bytes = ((double)std::min<int64_t>((int64_t)V * NB, nnz) + (double)nnz / kSegment) * ctx->ldk * sizeof(double);
+        int per_cu = 0;
+#define SWEEP_OCC(NCH, T, WPB, P) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sstats_sweep_kernel<NCH, T, WPB, P>, kWave * WPB, 0)
+        PYLDA_SWEEP_DISPATCH(ctx, c, SWEEP_OCC);
+#undef SWEEP_OCC
+        want_sweep = per_cu >= 1 && (ctx->gather_sweep == 2 || rows_bytes > budget);
+    }
+    const int64_t segment_cap = want_sweep ? kSweepSegment : kSegment;
     if (NB > 1) {
         // the documents of the postings come back through a page-locked buffer (0.8 GB at cfg 4: 16 ms instead of the
         // pageable copy's 0.3 s) and the cut runs on all host threads, term ranges side by side (it took 0.4 s)
@@ -867,7 +920,7 @@ int build_postings(pylda_corpus* c)
                 while (b < col_ptr[(size_t)v + 1]) {
                     const int32_t blk = (int32_t)(post_doc[(size_t)b] / per_block);
                     const int64_t block_end = ((int64_t)blk + 1) * per_block;       // first document of the next block
-                    const int64_t cap = std::min<int64_t>(col_ptr[(size_t)v + 1], b + kSegment);
+                    const int64_t cap = std::min<int64_t>(col_ptr[(size_t)v + 1], b + segment_cap);
                     int64_t e = b + 1;
                     while (e < cap && post_doc[(size_t)e] < block_end) ++e;
                     out.begin.push_back(b);
@@ -914,9 +967,45 @@ int build_postings(pylda_corpus* c)
     c->nseg = (int64_t)seg_begin.size();
     c->gather_blocks = NB;
     c->rounds.clear();
+    c->sweep = false;
+    if (want_sweep && c->nseg > 0) {
+        // the persistent sweep: every wavefront owns a few terms, all workgroups walk the document blocks together
+        const int T = c->sweep_terms;
+        const int64_t nwaves = (int64_t)ctx->num_cu * c->sweep_wpb;
+        const int passes = c->sweep_passes;
+        // terms by posting count, largest first, dealt boustrophedon over the wavefronts: equal work per block
+        std::vector<int32_t> by_df((size_t)V);
+        std::iota(by_df.begin(), by_df.end(), 0);
+        std::stable_sort(by_df.begin(), by_df.end(), [&](int32_t a, int32_t b) {
+            return col_ptr[(size_t)a + 1] - col_ptr[(size_t)a] > col_ptr[(size_t)b + 1] - col_ptr[(size_t)b];
+        });
+        std::vector<int32_t> term_of((size_t)passes * nwaves * T, -1);
+        for (int64_t j = 0; j < V; ++j) {
+            const int64_t row = j / nwaves, col = (row & 1) ? nwaves - 1 - j % nwaves : j % nwaves;
+            term_of[(size_t)(((row / T) * nwaves + col) * T + row % T)] = by_df[(size_t)j];
+        }
+        std::vector<int32_t> seg_block_all((size_t)c->nseg);
+        run_on_threads(cut_threads, [&](int t) {
+            std::copy(pieces[(size_t)t].block.begin(), pieces[(size_t)t].block.end(), seg_block_all.begin() + pieces[(size_t)t].base);
+        });
+        A(dev_alloc(ctx, &c->d_seg_block, (size_t)c->nseg));
+        A(dev_alloc(ctx, &c->d_term_of, term_of.size()));
+        A(dev_alloc(ctx, &c->d_rendezvous, (size_t)1));
+        dev_free(c->d_entropy_partial);
+        A(dev_alloc(ctx, &c->d_entropy_partial, (size_t)passes * nwaves));
+        if (rc != PYLDA_OK) return rc;
+        if (hipMemcpy(c->d_seg_block, seg_block_all.data(), seg_block_all.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_term_of, term_of.data(), term_of.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(ctx, PYLDA_ERR_HIP, "postings: H2D copy failed");
+        c->sweep = true;
+        c->ent_blocks = (int64_t)passes * nwaves;
+        c->partial_rows = 0;
+    }
     const int64_t ldk_rows = ctx->ldk;
     auto blocks_of = [&](int n_words) { return ((int64_t)n_words * ldk_rows + 255) / 256; };
-    if (NB > 1 && c->nseg > 0) {
+    if (c->sweep) {
+        // (no partial rows, no execution order)
+    } else if (NB > 1 && c->nseg > 0) {
         // rounds: groups of consecutive pieces (contiguous term ranges), each within the budget of partial rows
         const double row_bytes = (double)ctx->ldk * sizeof(double);
         const double budget = ctx->gather_round_mb > 0 ? (double)ctx->gather_round_mb * 1048576.0 : 4.0 * 1073741824.0;
@@ -982,17 +1071,21 @@ int build_postings(pylda_corpus* c)
     } else {
         c->rounds.push_back(Round{0, c->nseg, 0, V, 0, c->nseg, 0, blocks_of(V)});
     }
-    c->partial_rows = 0;
-    for (const Round& r : c->rounds) c->partial_rows = std::max(c->partial_rows, r.seg_hi - r.seg_lo);
-    c->ent_blocks = c->rounds.back().ent_first + c->rounds.back().ent_blocks;
+    if (!c->sweep) {
+        c->partial_rows = 0;
+        for (const Round& r : c->rounds) c->partial_rows = std::max(c->partial_rows, r.seg_hi - r.seg_lo);
+        c->ent_blocks = c->rounds.back().ent_first + c->rounds.back().ent_blocks;
+    }
     timer.lap("XCD execution order");
     A(dev_alloc(ctx, &c->d_seg_begin, (size_t)c->nseg));
     A(dev_alloc(ctx, &c->d_seg_end, (size_t)c->nseg));
     A(dev_alloc(ctx, &c->d_word_seg_ptr, (size_t)V + 1));
     timer.lap("segment array allocations");
-    A(dev_alloc(ctx, &c->d_partial, (size_t)c->partial_rows * ctx->ldk));
-    dev_free(c->d_entropy_partial);
-    A(dev_alloc(ctx, &c->d_entropy_partial, (size_t)c->ent_blocks));
+    if (!c->sweep) {
+        A(dev_alloc(ctx, &c->d_partial, (size_t)c->partial_rows * ctx->ldk));
+        dev_free(c->d_entropy_partial);
+        A(dev_alloc(ctx, &c->d_entropy_partial, (size_t)c->ent_blocks));
+    }
     if (rc != PYLDA_OK) return rc;
     timer.lap("partial rows allocation");
     auto H2D = [&](void* dst, const void* src, size_t bytes) {
@@ -1041,9 +1134,42 @@ void launch_gather(pylda_ctx* ctx, pylda_corpus* c, const pylda_corpus::Round& r
 #undef GATHER_ARGS
 }
 
+void fill_sweep_params(pylda_ctx* ctx, pylda_corpus* c, SweepParams& sp)
+{
+    sp.seg_begin = c->d_seg_begin;
+    sp.seg_end = c->d_seg_end;
+    sp.seg_block = c->d_seg_block;
+    sp.word_seg_ptr = c->d_word_seg_ptr;
+    sp.post_doc = c->d_post_doc;
+    sp.post_pos = c->d_post_pos;
+    sp.tfinal = c->d_tfinal;
+    sp.rfinal = c->d_rfinal;
+    sp.expElog = ctx->d_expElog;
+    sp.expElog_elog = ctx->d_expElog_elog;
+    sp.sstats = ctx->d_sstats;
+    sp.entropy_partial = c->d_entropy_partial;
+    sp.term_of = c->d_term_of;
+    sp.passes = c->sweep_passes;
+    sp.NB = c->gather_blocks;
+    sp.rendezvous = c->d_rendezvous;
+    sp.spin_limit = (unsigned)ctx->sweep_spin;       // (4000 ~ 5 ms: a rendezvous that does not complete costs L2 locality, nothing else)
+}
+
 int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
 {
     const int ldk = ctx->ldk;
+    if (c->sweep) {
+        SweepParams sp;
+        fill_sweep_params(ctx, c, sp);
+        (void)hipMemsetAsync(c->d_rendezvous, 0, sizeof(unsigned), ctx->stream);
+#define SWEEP_LAUNCH(NCH, T, WPB, P) \
+    hipLaunchKernelGGL((sstats_sweep_kernel<NCH, T, WPB, P>), dim3((unsigned)ctx->num_cu), dim3(kWave * WPB), 0, ctx->stream, sp)
+        PYLDA_SWEEP_DISPATCH(ctx, c, SWEEP_LAUNCH);
+#undef SWEEP_LAUNCH
+        hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_entropy_partial, c->ent_blocks, c->d_scalars + 2);
+        HIP_TRY(ctx, hipGetLastError());
+        return PYLDA_OK;
+    }
     for (const pylda_corpus::Round& r : c->rounds) {
         if (r.seg_hi > r.seg_lo) {
             if (c->wide_pos) launch_gather<int64_t>(ctx, c, r);
@@ -1261,6 +1387,10 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     } else if (!strcmp(name, "quilt_odd")) {
         ctx->quilt_odd = value != 0;
         ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "sweep_spin")) {
+        ctx->sweep_spin = (int)std::max<int64_t>(0, value);
+    } else if (!strcmp(name, "gather_sweep")) {      // (takes effect for corpora whose postings are built afterwards)
+        ctx->gather_sweep = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     } else if (!strcmp(name, "gather_round_mb")) {   // (takes effect for corpora whose postings are built afterwards)
         ctx->gather_round_mb = (int)std::max<int64_t>(0, value);
     } else if (!strcmp(name, "slab_uber")) {
@@ -1429,6 +1559,7 @@ void pylda_corpus_destroy(pylda_corpus* c)
     if (c->d_post_pos) (void)hipFree(c->d_post_pos);
     c->d_post_pos = nullptr;
     dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial); dev_free(c->d_exec_order);
+    dev_free(c->d_seg_block); dev_free(c->d_term_of); dev_free(c->d_rendezvous);
     delete c;
 }
 
@@ -2116,6 +2247,7 @@ int64_t pylda_corpus_layout(pylda_corpus* c, const char* name)
     if (!strcmp(name, "gather_blocks")) return c->have_postings ? c->gather_blocks : 0;
     if (!strcmp(name, "gather_segments")) return c->have_postings ? c->nseg : 0;
     if (!strcmp(name, "gather_rounds")) return c->have_postings ? (int64_t)c->rounds.size() : 0;
+    if (!strcmp(name, "gather_sweep_passes")) return c->have_postings && c->sweep ? c->sweep_passes : 0;
     if (!strcmp(name, "gather_partial_rows")) return c->have_postings ? c->partial_rows : 0;
     return fail(c->ctx, PYLDA_ERR_INVALID, "corpus_layout: unknown name '%s'", name);
 }

@@ -417,6 +417,7 @@ def test_statistics_gather_in_rounds(capi, ap_train, K, blocks):
     got = {}
     for budget in (0, 1):
         ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_sweep", 0)
         ctx.set_option("gather_blocks", blocks)
         ctx.set_option("gather_round_mb", budget)
         corpus = ctx.corpus(ptr, tid, tct)
@@ -431,6 +432,43 @@ def test_statistics_gather_in_rounds(capi, ap_train, K, blocks):
     assert got[1][2] >= 3 and got[1][3] <= got[0][3] // 3, got[1][2:]      # (a round holds at least one of the cut's 8 pieces)
     assert np.array_equal(got[0][0], got[1][0])
     assert abs(got[0][1] - got[1][1]) <= 1e-13 * abs(got[0][1])          # (the entropy partials are cut differently)
+
+
+@pytest.mark.parametrize("K,blocks,wide", [(128, 16, 0), (256, 8, 0), (100, 24, 1), (200, 40, 0)])
+def test_statistics_gather_as_a_persistent_sweep(capi, ap_train, K, blocks, wide):
+    """sstats_sweep.h: every wavefront owns a few terms and keeps their accumulators in registers while all
+    workgroups walk the document blocks together - no partial rows.  Against the dispatch-paced gather (same terms,
+    another summation order), the oracle, bitwise repeatable; the corpus likelihood of the training fast path comes
+    out of the same pass."""
+    from oracle import c_oracle
+    g = ap_train
+    rng = np.random.default_rng(K * 3 + blocks)
+    ptr = g["doc_ptr"][:801]
+    tid, tct = g["term_id"][:ptr[-1]], g["term_ct"][:ptr[-1]]
+    eta = rng.gamma(100.0, 0.01, (K, 6806))
+    alpha = rng.uniform(0.05, 1.0, K)
+    got = {}
+    for sweep in (0, 1, 1):
+        ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_sweep", 2 * sweep)            # (2: whatever the size of the partial rows)
+        ctx.set_option("gather_blocks", blocks)
+        ctx.set_option("wide_postings", wide)
+        corpus = ctx.corpus(ptr, tid, tct)
+        res = ctx.estep_host(corpus, alpha, eta)
+        assert (corpus.layout("gather_sweep_passes") >= 1) == bool(sweep)
+        assert corpus.layout("gather_partial_rows") == (0 if sweep else corpus.layout("gather_segments"))
+        ctx.set_option("doc_values", 0)
+        ctx.estep(corpus)
+        fast = ctx.estep_results(corpus)[0]
+        assert abs(fast - res["document_log_likelihood"]) < 1e-11 * abs(res["document_log_likelihood"])
+        got.setdefault(sweep, []).append((res["sstats"], fast))
+        corpus.close()
+        ctx.close()
+    ref = c_oracle.e_step(alpha, eta, ptr, tid, tct)
+    assert np.max(np.abs(got[1][0][0] - got[0][0][0])) < 1e-11
+    assert np.max(np.abs(got[1][0][0] - ref["sstats"])) < SSTATS_ATOL
+    assert abs(got[1][0][0].sum() - tct.sum()) < 1e-7
+    assert np.array_equal(got[1][0][0], got[1][1][0]) and got[1][0][1] == got[1][1][1]
 
 
 def test_runs_on_the_system_hip_runtime_without_torch():
