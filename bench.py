@@ -77,7 +77,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "pylda_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.startswith("estep_") or f in ("sstats_kernels.h", "doc_terms.h"):
+        if f.startswith("estep_") or f in ("sstats_kernels.h", "sstats_sweep.h", "doc_terms.h"):
             h.update(f.encode())
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]

@@ -219,3 +219,54 @@ def test_bench_all_cores_cpu_leg_runs_workers_and_adds_rates():
         np.full(K, 0.1), rng.gamma(100.0, 0.01, (K, V)), np.array(ptr, np.int64),
         np.concatenate(ids).astype(np.int32), np.concatenate(cts).astype(np.int32), 0.2, 3, docs_per_worker=20)
     assert workers == 3 and 15 <= done <= 60 and rate > 0
+
+
+def test_traffic_record_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py reports roofline.traffic from profiles/traffic_<workload>.json only while the sha256 of the kernel
+    sources equals the one the rocprofv3 passes were made with; otherwise null and a STALE note."""
+    import json
+    import bench
+    want = bench.kernel_source_hash()
+    assert len(want) == 16 and want == bench.kernel_source_hash()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "pylda_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "pylda_amd" / "csrc" / "estep_x.h").write_text("// kernel\n")
+    now = bench.kernel_source_hash()
+    assert now != want
+    path = tmp_path / "profiles" / "traffic_synth100k.json"
+    path.write_text(json.dumps({"hbm_bytes_per_launch": 123, "kernel_source_hash": now}))
+    assert bench.traffic_record("synth100k")[0] == 123
+    (tmp_path / "pylda_amd" / "csrc" / "estep_x.h").write_text("// kernel, edited\n")
+    value, note = bench.traffic_record("synth100k")
+    assert value is None and "STALE" in note
+    assert bench.traffic_record("nips") == (None, None) and bench.traffic_record(None) == (None, None)
+
+
+def test_launch_train_flags_and_launcher_command():
+    """The reference's flags (launch_train.py:31-62) plus --gpus / --share_gpu; `--gpus N` turns into a
+    torch.distributed.run command line on 127.0.0.1 that re-runs the same module with the same arguments."""
+    from pylda_amd import cli
+    names = [f[0] for f in cli.TRAIN_FLAGS]
+    for flag in ("input_directory", "output_directory", "number_of_topics", "training_iterations", "snapshot_interval",
+                 "alpha_alpha", "alpha_beta", "inference_mode", "gpus"):
+        assert flag in names
+    argv = cli._launcher_argv(4, ["--input_directory=x/", "--gpus=4"])
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node" in argv
+    assert argv[argv.index("--nproc-per-node") + 1] == "4" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[-4:] == ["-m", "pylda_amd.launch_train", "--input_directory=x/", "--gpus=4"]
+
+
+def test_shards_of_a_corpus_smaller_than_the_world():
+    """More ranks than documents: trailing ranks get empty, well-formed shards."""
+    from pylda_amd.corpus import shard_bounds, shard_csr
+    ptr = np.array([0, 3, 5], np.int64)
+    ids, cts = np.arange(5, dtype=np.int32), np.ones(5, np.int32)
+    bounds = shard_bounds(ptr, 4)
+    assert bounds[0] == 0 and bounds[-1] == 2 and all(a <= b for a, b in zip(bounds, bounds[1:]))
+    seen = 0
+    for rank in range(4):
+        sp, si, sc, (lo, hi) = shard_csr(ptr, ids, cts, 4, rank)
+        assert sp[0] == 0 and sp[-1] == si.size == sc.size and len(sp) == hi - lo + 1
+        seen += hi - lo
+    assert seen == 2
