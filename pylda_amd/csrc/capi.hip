@@ -500,8 +500,9 @@ int launch_slab_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 
 // The slab classes of a small corpus as ONE dispatch (estep_slab.h, estep_slab_uber_kernel): the classes from index
 // `from` to the end of the plan, or -1.  Eligible: at least two classes, all of the slab family with the same slab
-// width and at most 4 words per lane at 16-topic slabs (the 6-word instantiation needs more than 256 registers: one
-// wavefront per SIMD - it would halve the residency of everybody), every wavefront resident at once at two per SIMD.
+// width, few enough wavefronts to be resident at once at two per SIMD (with documents of 6 words per lane in the
+// launch the kernel needs more than 256 registers - one wavefront per SIMD, two rounds of residency at most - and still
+// beats a second stream).
 int slab_uber_from(const pylda_ctx* ctx, const pylda_corpus* c)
 {
     if (!ctx->slab_uber || c->plan.size() < 2) return -1;
@@ -510,7 +511,7 @@ int slab_uber_from(const pylda_ctx* ctx, const pylda_corpus* c)
     int64_t docs = 0;
     while (from > 0) {
         const Launch& L = c->plan[(size_t)from - 1];
-        if (L.variant != kSlab || L.rk != rk || (rk == 16 && L.rn > 4) || (rk == 32 && L.rn > 2)) break;
+        if (L.variant != kSlab || L.rk != rk || (rk == 16 && L.rn > 6) || (rk == 32 && L.rn > 2)) break;
         docs += L.count;
         --from;
     }
@@ -540,7 +541,9 @@ int launch_slab_uber(pylda_ctx* ctx, const EstepParams& p, const pylda_corpus* c
         lds = std::max(lds, need);
     }
     cls.first[cls.n] = (int)docs;
-    auto kern = estep_slab_uber_kernel<W, RK>;
+    bool has_long = false;
+    for (int i = 0; i < cls.n; ++i) has_long = has_long || cls.rn[i] > 4;
+    auto kern = (RK == 16 && has_long) ? estep_slab_uber_kernel<W, RK, true> : estep_slab_uber_kernel<W, RK, false>;
     if (lds > 64 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)docs), dim3(kWave * W), lds, ctx->stream, p, cls);

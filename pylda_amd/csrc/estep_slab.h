@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_kernel(EstepParams p)
 // Small corpora: every launch class of the slab family in ONE dispatch.  A corpus of a few thousand documents
 // (associated-press: 2000 documents in five words-per-lane classes) cannot fill the chip; run as five kernels
 // on five streams it pays the fork / join over the streams (2-3 x the slowest class, profiles/r01_ap_k10_summary.txt)
-// for nothing: all its wavefronts are resident at once even at the register budget of the largest class.  The
+// for nothing.  The
 // workgroup picks its instantiation from its position in the (longest first) schedule; the switch is uniform.
 struct SlabUberClasses {
     int n;            // classes
@@ -303,7 +303,11 @@ struct SlabUberClasses {
     int rn[6];        // ... and runs RN = rn[i] words per lane
 };
 
-template <int W, int RK>
+// LONG: the 6-words-per-lane instantiation is part of the switch (16-topic slabs).  It needs more than 256 registers -
+// one wavefront per SIMD for EVERY workgroup of the launch - so it is only compiled into the kernel used when a corpus
+// has such documents (associated-press: 57 of 2000; in their own launch beside the others they cost a fork / join over
+// two streams: document kernels 0.160 ms against 0.129 in one dispatch).
+template <int W, int RK, bool LONG>
 __global__ __launch_bounds__(kWave* W) void estep_slab_uber_kernel(EstepParams p, SlabUberClasses cls)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -322,7 +326,9 @@ __global__ __launch_bounds__(kWave* W) void estep_slab_uber_kernel(EstepParams p
         case 2: slab_document<W, RK, 2>(p, doc, smem); break;
         case 3: slab_document<W, RK, 3>(p, doc, smem); break;
         case 4: slab_document<W, RK, 4>(p, doc, smem); break;
-        default: slab_document<W, RK, 6>(p, doc, smem); break;
+        default:
+            if constexpr (LONG) slab_document<W, RK, 6>(p, doc, smem);
+            break;
         }
     }
 }
