@@ -1169,8 +1169,7 @@ int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
     hipLaunchKernelGGL((sstats_sweep_kernel<NCH, T, WPB, P>), dim3((unsigned)ctx->num_cu), dim3(kWave * WPB), 0, ctx->stream, sp)
         PYLDA_SWEEP_DISPATCH(ctx, c, SWEEP_LAUNCH);
 #undef SWEEP_LAUNCH
-        hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_entropy_partial, c->ent_blocks, c->d_scalars + 2);
-        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipGetLastError());       // (the entropy partials are summed with the likelihoods: pylda_estep)
         return PYLDA_OK;
     }
     for (const pylda_corpus::Round& r : c->rounds) {
@@ -1183,9 +1182,7 @@ int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
                                c->d_word_seg_ptr, c->d_partial, ctx->d_expElog, ctx->d_expElog_elog, r.w_first, r.n_words, ldk,
                                r.seg_lo, ctx->d_sstats, c->d_entropy_partial + r.ent_first);
     }
-    hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_entropy_partial,
-                       c->ent_blocks, c->d_scalars + 2);
-    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipGetLastError());           // (the entropy partials are summed with the likelihoods: pylda_estep)
     return PYLDA_OK;
 }
 
@@ -1775,7 +1772,10 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         join();
     }
     // the document terms the register kernels left out on the training fast path (status 3; doc_terms.h)
-    if (!heldout && !p.want_doc_ll && c->D > 0)
+    bool leaves_terms = false;          // (slab and generic kernels always finish their documents themselves)
+    for (const Launch& L : c->plan)
+        leaves_terms = leaves_terms || L.variant == kQuad || L.variant == kQuilt || L.variant == kQwide || L.variant == kQfuse || L.variant == kQfusek;
+    if (!heldout && !p.want_doc_ll && c->D > 0 && leaves_terms)
         hipLaunchKernelGGL(doc_terms_kernel, dim3((unsigned)((c->D + 3) / 4)), dim3(256), 0, ctx->stream, p, c->D);
     close_bracket(doc_bracket, ctx->stream);
     if (ctx->profiling) ctx->estep_calls += 1;
@@ -1805,10 +1805,9 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         hipLaunchKernelGGL(estep_logspace_kernel, dim3(grid), dim3(256), logspace_lds_bytes(K),
                            ctx->stream, p, ctx->d_elog, ctx->d_sstats, c->d_flag_list, c->d_flag_count);
     }
-    hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_doc_ll, c->D,
-                       c->d_scalars);
-    hipLaunchKernelGGL(vector_sum_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_doc_wll, c->D,
-                       c->d_scalars + 1);
+    hipLaunchKernelGGL(vector_sum3_kernel, dim3(heldout ? 2 : 3), dim3(1024), 0, ctx->stream, SumJob{c->d_doc_ll, c->D, c->d_scalars},
+                       SumJob{c->d_doc_wll, c->D, c->d_scalars + 1},
+                       SumJob{c->d_entropy_partial, heldout ? 0 : c->ent_blocks, heldout ? nullptr : c->d_scalars + 2});
     HIP_TRY(ctx, hipGetLastError());
     c->estep_done = true;
     c->last_heldout = heldout;

@@ -129,4 +129,22 @@ __global__ __launch_bounds__(1024) void vector_sum_kernel(const double* __restri
     if (threadIdx.x == 0) out[0] = s;
 }
 
+// The three corpus-level sums of an E-step (document log-likelihood, words log-likelihood, entropy partials of the
+// statistics pass) in one launch: workgroup b sums vector b (a small corpus' E-step is a chain of kernel boundaries).
+struct SumJob {
+    const double* x;
+    int64_t n;
+    double* out;
+};
+__global__ __launch_bounds__(1024) void vector_sum3_kernel(SumJob a, SumJob b, SumJob c)
+{
+    __shared__ double scratch[16];
+    const SumJob job = blockIdx.x == 0 ? a : blockIdx.x == 1 ? b : c;
+    if (!job.out) return;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < job.n; i += 1024) s += job.x[i];
+    s = block_sum<1024>(s, scratch);
+    if (threadIdx.x == 0) job.out[0] = s;
+}
+
 }  // namespace pylda
