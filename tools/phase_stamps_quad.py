@@ -2,7 +2,7 @@
 """Phase timing of the quad kernel's inner loop with s_memtime stamps (development tool).
 
     python tools/phase_stamps_quad.py [-DNAME=value ...]      # builds an instrumented COPY under .scratch/dbgq
-    gpurun -- 'cd .scratch/dbgq && python run_dbg.py [cfg3|cfg4] [nmin nmax] [name=value ...]'
+    gpurun -- 'cd .ab/dbgq && python run_dbg.py [cfg3|cfg4] [nmin nmax] [name=value ...]'
 
 The copy is compiled with -DPYLDA_QUAD_STAMPS=1 (estep_quad.h: QUAD_STAMP); the working tree's library
 is not touched.  Stamps drain the LDS queue, so absolute times are ~10-15 % high, the split between the
@@ -12,7 +12,7 @@ cycles per document, and where the hardware placed the wavefronts (SIMD of wavef
 workgroup)."""
 import os, shutil, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(root, ".scratch", "dbgq")
+dst = os.path.join(root, ".ab", "dbgq")
 shutil.rmtree(dst, ignore_errors=True)
 os.makedirs(dst)
 for d in ("pylda_amd", "include"):
