@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Phase timing of the quilt kernel's inner loop with s_memtime stamps (development tool).
 
-    python tools/phase_stamps.py            # builds an instrumented COPY under .scratch/dbg
-    gpurun -- 'cd .scratch/dbg && python run_dbg.py'
+    python tools/phase_stamps.py            # builds an instrumented COPY under .ab/dbg
+    gpurun -- 'cd .ab/dbg && python run_dbg.py'
 
 The working tree is not touched: pylda_amd/ is copied, estep_quilt.h of the copy gets a stamp
 (s_waitcnt lgkmcnt(0); s_memtime) at each phase boundary, the per-phase sums of wavefront 0 (a
@@ -14,7 +14,7 @@ the kernel changes, the assertions say which anchor to update.
 """
 import os, shutil, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(root, ".scratch", "dbg")
+dst = os.path.join(root, ".ab", "dbg")
 shutil.rmtree(dst, ignore_errors=True)
 os.makedirs(dst)
 for d in ("pylda_amd", "include"):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase timing of the quad kernel's inner loop with s_memtime stamps (development tool).
 
-    python tools/phase_stamps_quad.py [-DNAME=value ...]      # builds an instrumented COPY under .scratch/dbgq
+    python tools/phase_stamps_quad.py [-DNAME=value ...]      # builds an instrumented COPY under .ab/dbgq
     gpurun -- 'cd .ab/dbgq && python run_dbg.py [cfg3|cfg4] [nmin nmax] [name=value ...]'
 
 The copy is compiled with -DPYLDA_QUAD_STAMPS=1 (estep_quad.h: QUAD_STAMP); the working tree's library
