@@ -7,8 +7,8 @@
 //     row -> dot with t -> wavefront sum -> r = c / nrm -> q += r * row
 //
 // reads each row ONCE per inner iteration from L2 / Infinity Cache and needs no LDS transpose.  No word stays on
-// chip (a 230-term document at K = 1000 is 1.8 MB); two row buffers (2 x 2 NP VGPR pairs) are in flight per
-// wavefront, t and the topic sums live in registers.  Gamma phase: KT <= 1024 topics on the workgroup's 512
+// chip (a 230-term document at K = 1000 is 1.8 MB); four row buffers and words in pairs up to stride 768, two buffers
+// and single words above (2 x 2 NP VGPR pairs each) per wavefront, t and the topic sums live in registers.  Gamma phase: KT <= 1024 topics on the workgroup's 512
 // threads, two topics per thread (tid, tid + 512).
 //
 // Layout: 8 wavefronts per document, word n belongs to wavefront n % 8, slot n / 8 (documents up to
@@ -63,16 +63,21 @@ struct StreamRow {
         if constexpr (NP > 6) piece_request<2048>(p[6], hi);
         if constexpr (NP > 7) piece_request<3072>(p[7], hi);
     }
-    // OTHER_IN_FLIGHT: the other buffer's NP loads were requested after this one's and may stay outstanding
-    template <bool OTHER_IN_FLIGHT>
+    // ROWS_NEWER: rows requested after this one (their NP loads each may stay outstanding)
+    template <int ROWS_NEWER>
     __device__ __forceinline__ void wait()
     {
-        static_assert(NP >= 5 && NP <= 8, "five to eight pieces");
-        if constexpr (!OTHER_IN_FLIGHT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if constexpr (NP == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if constexpr (NP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if constexpr (NP == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        static_assert(NP >= 5 && NP <= 8 && ROWS_NEWER >= 0 && ROWS_NEWER <= 2 && NP * ROWS_NEWER <= 16, "vmcnt immediates below");
+        constexpr int OUT = NP * ROWS_NEWER;
+        if constexpr (OUT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (OUT == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if constexpr (OUT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (OUT == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else if constexpr (OUT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (OUT == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if constexpr (OUT == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr (OUT == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 #pragma unroll
         for (int jj = 0; jj < NP; ++jj) asm volatile("" : "+v"(p[jj]));      // the values exist from here on
     }
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfusek_kernel(EstepParams p)
     using L = QfusekLds<NP>;
     constexpr int W = 8, NT = 512, KT = 128 * NP, KRL = 2 * NP;
     constexpr int TPT = (KT + NT - 1) / NT;          // topics per thread in the gamma phase (2)
+    constexpr bool PAIRS = NP <= 6;                  // four row buffers fit the registers: words go in pairs
     static_assert(NP >= 5 && NP <= 8 && TPT == 2, "table stride 640 .. 1024");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sp = reinterpret_cast<double*>(smem + L::sp);
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfusek_kernel(EstepParams p)
     const int64_t lo = p.doc_ptr[doc];
     const int N = (int)(p.doc_ptr[doc + 1] - lo);
     const int S = (N + W - 1) / W;                          // word slots per wavefront: word n = slot * 8 + wave
-    const int Spad = (S + 1) & ~1;                          // whole trips of two
+    const int Spad = PAIRS ? (S + 3) & ~3 : (S + 1) & ~1;   // whole trips of four (pairs) / two
     int* myids = reinterpret_cast<int*>(smem + L::ids) + wave * kQfMaxSlots;
     double* mycnt = reinterpret_cast<double*>(smem + L::cnt) + wave * kQfMaxSlots;
     double* myrr = reinterpret_cast<double*>(smem + L::rr) + wave * kQfMaxSlots;
@@ -186,17 +192,67 @@ __global__ __launch_bounds__(512, 2) void estep_qfusek_kernel(EstepParams p)
                 q[2 * jj + 1] = fma(r, g.p[jj].y, q[2 * jj + 1]);
             }
         };
-        if (Spad > 0) {
+        if constexpr (PAIRS) {
+            // words in pairs (estep_qfuse.h): one swap level folds the two words' per-lane dots into one register, the
+            // remaining reduction levels, the range check and the reciprocal run once for both; four row buffers, the
+            // next pair in flight while this one is reduced (up to stride 768: 4 x 12 VGPR pairs)
+            auto word_pair = [&](const StreamRow<NP>& ga, const StreamRow<NP>& gb, int slot) {
+                double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < NP; ++jj) {
+                    a0 = fma(ga.p[jj].x, tq[2 * jj], a0);
+                    a1 = fma(ga.p[jj].y, tq[2 * jj + 1], a1);
+                    b0 = fma(gb.p[jj].x, tq[2 * jj], b0);
+                    b1 = fma(gb.p[jj].y, tq[2 * jj + 1], b1);
+                }
+                const double nrm = half_wave_sum(swap32_add(a0 + a1, b0 + b1));
+                const double cnt = mycnt[slot + (c >> 5)];
+                const bool live = cnt > 0.0;
+                if (live && !(nrm > 1e-280 && nrm < 1e300)) bad = 1;
+                const double r = live ? cnt * rcp_newton(nrm) : 0.0;
+                if ((c & 31) == 0) myrr[slot + (c >> 5)] = r;
+                const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(r), __double2loint(r), false, false);
+                const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(r), __double2hiint(r), false, false);
+                const double rA = __hiloint2double(hi[0], lo[0]), rB = __hiloint2double(hi[1], lo[1]);
+#pragma unroll
+                for (int jj = 0; jj < NP; ++jj) {
+                    q[2 * jj] = fma(rA, ga.p[jj].x, q[2 * jj]);
+                    q[2 * jj + 1] = fma(rA, ga.p[jj].y, q[2 * jj + 1]);
+                }
+#pragma unroll
+                for (int jj = 0; jj < NP; ++jj) {
+                    q[2 * jj] = fma(rB, gb.p[jj].x, q[2 * jj]);
+                    q[2 * jj + 1] = fma(rB, gb.p[jj].y, q[2 * jj + 1]);
+                }
+            };
+            if (Spad > 0) {
+                StreamRow<NP> g0, g1, g2, g3;
+                g0.request(row_address(0));
+                g1.request(row_address(1));
+                g2.request(row_address(2));
+                g3.request(row_address(3));
+                int s = 0;
+                for (; s + 4 < Spad; s += 4) {      // full trips: a pair of buffers is re-requested four slots ahead
+                    g0.template wait<2>(); g1.template wait<2>(); word_pair(g0, g1, s + 0);
+                    g0.request(row_address(s + 4)); g1.request(row_address(s + 5)); __builtin_amdgcn_sched_barrier(0);
+                    g2.template wait<2>(); g3.template wait<2>(); word_pair(g2, g3, s + 2);
+                    g2.request(row_address(s + 6)); g3.request(row_address(s + 7)); __builtin_amdgcn_sched_barrier(0);
+                }
+                g0.template wait<2>(); g1.template wait<2>(); word_pair(g0, g1, s + 0);      // last trip: the pipeline drains
+                __builtin_amdgcn_sched_barrier(0);
+                g2.template wait<0>(); g3.template wait<0>(); word_pair(g2, g3, s + 2);
+            }
+        } else if (Spad > 0) {
             StreamRow<NP> g0, g1;
             g0.request(row_address(0));
             g1.request(row_address(1));
             int s = 0;
             for (; s + 2 < Spad; s += 2) {          // full trips: a buffer is re-requested two slots ahead
-                g0.template wait<true>(); word(g0, s + 0); g0.request(row_address(s + 2)); __builtin_amdgcn_sched_barrier(0);
-                g1.template wait<true>(); word(g1, s + 1); g1.request(row_address(s + 3)); __builtin_amdgcn_sched_barrier(0);
+                g0.template wait<1>(); word(g0, s + 0); g0.request(row_address(s + 2)); __builtin_amdgcn_sched_barrier(0);
+                g1.template wait<1>(); word(g1, s + 1); g1.request(row_address(s + 3)); __builtin_amdgcn_sched_barrier(0);
             }
-            g0.template wait<true>(); word(g0, s + 0); __builtin_amdgcn_sched_barrier(0);      // last trip: the pipeline drains
-            g1.template wait<false>(); word(g1, s + 1);
+            g0.template wait<1>(); word(g0, s + 0); __builtin_amdgcn_sched_barrier(0);      // last trip: the pipeline drains
+            g1.template wait<0>(); word(g1, s + 1);
         }
         // per-wavefront topic partials: lane c, register j  <->  topic 2c + 128*(j>>1) + (j&1)
 #pragma unroll
