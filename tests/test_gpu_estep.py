@@ -604,7 +604,7 @@ def test_error_reporting(capi):
 
 
 def test_randomised_parity_sweep(capi):
-    """tools/fuzz_parity.py for 30 s: K from 1 to 512, documents of 1 to ~600 terms, alpha from 0.005 to 1.5, three
+    """tools/fuzz_parity.py for 30 s: K from 1 to 1100, documents of 1 to ~600 terms, alpha from 0.005 to 1.5, three
     thresholds, random settings of the statistics gather - every document stops on the C oracle's inner iteration
     (the tolerances on log-likelihood, gamma, statistics and the fast path are asserted inside the sweep)."""
     import importlib.util

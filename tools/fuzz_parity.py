@@ -1,5 +1,5 @@
 """Randomised parity sweep: python tools/fuzz_parity.py [seconds] [seed]
-Random K, V, document lengths and alpha; per-document log-likelihood / gamma / iterations against the C oracle,
+Random K (1 .. 1100), V, document lengths, alpha and settings of the statistics pass; per-document log-likelihood / gamma / iterations against the C oracle,
 and the training fast path (doc_values=0: document-terms pass) against the complete per-document values.
 tests/test_gpu_estep.py::test_randomised_parity_sweep runs sweep(30 s) in the GPU suite."""
 import sys, time, numpy as np
@@ -14,7 +14,8 @@ def sweep(budget=60.0, seed=0, verbose=True):
     cases = worst_ll = worst_g = worst_fast = worst_ss = 0
     flips = docs = 0
     while time.time() - t0 < budget:
-        K = int(rng.choice([1, 2, 7, 10, 16, 31, 33, 64, 65, 100, 127, 128, 129, 160, 192, 200, 255, 256, 257, 300, 384, 400, 500, 512]))
+        K = int(rng.choice([1, 2, 7, 10, 16, 31, 33, 64, 65, 100, 127, 128, 129, 160, 192, 200, 255, 256, 257, 300, 384, 400, 500, 512,
+                            513, 640, 700, 768, 800, 1000, 1024, 1100]))
         V = int(rng.integers(max(20, K // 4), 5000))
         D = int(rng.integers(1, 40))
         mean_len = float(rng.choice([3, 20, 80, 150, 200, 215, 240, 300, 500]))
@@ -33,6 +34,10 @@ def sweep(budget=60.0, seed=0, verbose=True):
         ctx = _capi.Context(K, V)
         ctx.set_option("gather_blocks", int(rng.choice([-1, 0, 8, 16, 40])))      # statistics gather: automatic / unblocked / forced blocks
         ctx.set_option("gather_rows", int(rng.choice([0, 1, 2, 2])))
+        ctx.set_option("gather_sweep", int(rng.choice([0, 1, 2, 2])))               # persistent sweep where the gather is blocked
+        ctx.set_option("gather_round_mb", int(rng.choice([0, 0, 1])))               # ... or rounds over term ranges
+        ctx.set_option("slab_uber", int(rng.choice([0, 1, 1])))
+        ctx.set_option("wide_postings", int(rng.choice([0, 0, 1])))
         corpus = ctx.corpus(ptr, ids, cts)
         out = ctx.estep_host(corpus, alpha, eta, 50, tol, False)
         ctx.set_option("doc_values", 0)
