@@ -21,8 +21,14 @@ class _DevicePointer(object):
 
 
 def device_tensor(ptr, shape, device):
+    """Zero-copy torch view of `shape` doubles at device address `ptr`.  Fails loudly if torch made a copy instead
+    (a pointer it attributes to another device): a collective on a copy would silently reduce nothing."""
     import torch
-    return torch.as_tensor(_DevicePointer(ptr, shape), device=device)
+    t = torch.as_tensor(_DevicePointer(ptr, shape), device=device)
+    if t.data_ptr() != int(ptr):
+        raise RuntimeError("pylda_amd.distributed: torch copied the library's device buffer (pointer %#x on %s) instead of "
+                           "wrapping it" % (int(ptr), device))
+    return t
 
 
 def bind_to_torch_stream(ctx):
