@@ -14,7 +14,13 @@
 // Measured (tools/gather_ab.py): cfg 4 (3 passes x 240 blocks) 47.8 ms against 50.2 for the dispatch-paced gather in 12
 // rounds, without pacing (spin limit 0) 59.9; cfg 3 (1 pass x 24 blocks) 1.84 against 1.63 - a rendezvous costs ~25 us of
 // arrival skew (letting workgroups run one or two blocks ahead: 56-60 ms at cfg 4, the locality goes), so the sweep is
-// the default only where the partial rows would not fit their budget (option gather_sweep).
+// the default only where the partial rows would not fit their budget (option gather_sweep).  The rendezvous itself is
+// cheap (tools/rendezvous_bench.hip: 3.7 us for 256 workgroups on one counter, 2.4 with per-XCD counters, idle chip);
+// what a block costs beside its rows is the skew of the arrivals and the latency chain bounds -> postings -> r in
+// front of the rows.  A three-deep software pipeline of those stages over (block, group) items was built and measured:
+// its state no longer fits 128 registers beside the accumulators (scratch traffic inside the loop) - cfg 4 57.9 ms,
+// cfg 3 2.15 ms - so the groups of four stay.  L2-sized blocks (480 at cfg 4) lose to 240 for the same reason: the
+// per-block cost, not the fabric, is the larger term.
 //
 // The rendezvous is what keeps a block's rows (one L2's worth) hot in every XCD's L2 while all 256 CUs read them: each
 // row comes over the fabric once per XCD and pass instead of once per posting.  It carries NO data - everything the
