@@ -102,7 +102,14 @@ def _two_rank_worker(rank, world, port, out_dir, backend, one_gpu_each=False):
     m._verbose = False
     m._initialize_parsed(sp, si, sc, 6806, 10, 0.1, 1.0 / 6806, eta=g["eta"].copy())
     assert getattr(m._context(), "_torch_stream", None) is not None       # runs on a stream torch knows
-    trace = [m.learning() for _ in range(3)]
+    trace = []
+    for _ in range(3):
+        # a sentinel ahead of every iteration: ~25 ms of device time on the context's stream, so that the E-step's
+        # kernels START late.  A collective issued on any other stream would run while they are still queued and sum
+        # the statistics of the iteration before (zeros, the first time): the trajectory below would not match.
+        with torch.cuda.stream(m._context()._torch_stream):
+            torch.cuda._sleep(50_000_000)
+        trace.append(m.learning())
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), trace=np.array(trace), alpha=m._alpha_alpha,
              eta=m._eta, gamma=m._gamma, lo=lo, hi=hi)
     dist.destroy_process_group()
