@@ -52,6 +52,16 @@ namespace pylda {
 #ifndef PYLDA_QUAD_STAMPS
 #define PYLDA_QUAD_STAMPS 0
 #endif
+// Timing probes with UNCHANGED results (development builds, tools/ab_build.py): what a longer serial chain costs in
+// situ, as a bound on what shortening it could gain.  C2: the gamma phase's exp(psi(gamma) - c) evaluated twice in a
+// row (the second argument is gamma + 0 * first result).  T2: the second normaliser transpose read, written back and
+// read again (one more LDS round trip on the chain).
+#ifndef PYLDA_QUAD_PROBE_C2
+#define PYLDA_QUAD_PROBE_C2 0
+#endif
+#ifndef PYLDA_QUAD_PROBE_T2
+#define PYLDA_QUAD_PROBE_T2 0
+#endif
 #if PYLDA_QUAD_STAMPS
 #define QUAD_STAMP(j)                                                          \
     do {                                                                       \
@@ -355,6 +365,14 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             double2 h1[NPIECE];
 #pragma unroll
             for (int x = 0; x < NPIECE; ++x) h1[x] = mysrc[FL * x];
+#if PYLDA_QUAD_PROBE_T2
+            wave_lds_exchange();
+#pragma unroll
+            for (int x = 0; x < NPIECE; ++x) const_cast<double2*>(mysrc)[FL * x] = h1[x];
+            wave_lds_exchange();
+#pragma unroll
+            for (int x = 0; x < NPIECE; ++x) h1[x] = mysrc[FL * x];
+#endif
             const double cnt1 = count_of(1);
             // the reciprocal chain of the first chunk runs while the second transpose is in flight; the second
             // chunk's chain is placed behind the first 32 FMAs of pass B (which need r0 only)
@@ -463,7 +481,12 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
             QUAD_STAMP(11);                                               // gamma update, change into the fixed-point sum
+#if PYLDA_QUAD_PROBE_C2
+            const double t_probe = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
+            const double t_next = exp_digamma_minus_levels<true>(fma(t_probe, 0.0, gam), psi_total, coef_a, &coef_b);
+#else
             const double t_next = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
+#endif
             QUAD_STAMP(12);                                               // exp(psi(gamma) - psi(sum))
             tt[(buf ^ 1) * KT + ktid] = topic_live ? t_next : 0.0;
             if (ktid == 0) store_u64_hi(&chg[buf ^ 1], 0u);
