@@ -349,8 +349,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
 #pragma unroll
             for (int i = 0; i < R1; ++i) a1[i] = TL == 16 ? dot8_two_chains(B[8 + i], tq) : dot8(B[8 + i], tq);
             row_partial(StaticIndex<2>());
-            row_partial(StaticIndex<3>());
-            if constexpr (TWL > 0) request_row(0);                        // for pass B
+            row_partial(StaticIndex<3>());                                // (the last row stays in the buffer: pass B starts with it)
             double s0 = finish_sum(h0);
             asm volatile("" : "+v"(s0));                                  // h0 is dead from here on
             QUAD_STAMP(1);                                                // slots 8.., rows 2, 3, first transpose landed and summed
@@ -391,15 +390,17 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
 
         // B. q[k] over this lane's words (registers and LDS rows interleaved), then over the word groups
         double q[KRL];
-        auto row_topic_sums = [&](auto idx) {                // LDS slot t: q += r * row, next row requested
-            constexpr int t = decltype(idx)::value;
-            if constexpr (t < TWL) {
+        // Pass B walks the LDS slots BACKWARDS: the row pass A used last is still in the buffer, and the one this pass
+        // uses last (slot 0) stays there for pass A of the next iteration - 2 (TWL - 1) row requests per iteration
+        // instead of 2 TWL (with one LDS slot the row simply lives in the buffer)
+        auto row_topic_sums = [&](auto idx) {                // step u: LDS slot t = TWL - 1 - u: q += r * row, next row requested
+            constexpr int t = TWL - 1 - decltype(idx)::value;
+            if constexpr (t >= 0) {
                 lds_row_wait(rowbuf);
                 double row[8];
                 rowbuf.unpack(row);
                 row_bcast_fmac<2 * (R1 + t)>(q, r1, row);
-                if constexpr (t + 1 < TWL) request_row(t + 1);
-                else request_row(0);                                      // for pass A of the next iteration
+                if constexpr (t > 0) request_row(t - 1);
             }
         };
         {
