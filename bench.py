@@ -448,6 +448,72 @@ def host_contract_leg(vb):
             "note": "public e_step() / m_step() with host ndarrays (sufficient statistics K x V down and up again), best of 3"}
 
 
+XGMI_LINK_GBPS = 153.0           # one of a GPU's 7 peer links; a ring all-reduce is bound by one link
+
+
+def shard_proxy(job, args, step_ms_full):
+    """Single-GPU PROXY for the strong-scaling curve of cfg 4 (no multi-GPU node is available to this run): rank 0's
+    step at the shard sizes N = 2 / 4 / 8 would produce - 1M / N documents with the FULL K x V tables - measured on
+    this one GPU, plus a MODEL of the exchange (bytes / xGMI link figure, not overlapped).  Shows what does not
+    shrink with the shard: table preparation, the statistics pass over all V terms, the M-step, the all-reduce."""
+    import contextlib
+    import io
+    from pylda_amd import distributed
+    from pylda_amd.variational_bayes import VariationalBayes
+    rows = []
+    for n in (2, 4, 8):
+        wl = build_workload("synth1m", 0, n, job.device, args.extra_docs)
+        ptr, ids, cts, V, K = wl["ptr"], wl["ids"], wl["cts"], wl["V"], wl["K"]
+        np.random.seed(0)
+        eta0 = np.random.gamma(100., 1. / 100., (K, V))
+        vb = VariationalBayes(hyper_parameter_optimize_interval=1, device=job.local_rank)
+        vb._verbose = False
+        vb._initialize_parsed(ptr, ids, cts, V, K, 1.0 / K, 1.0 / V, eta=eta0)
+        ctx = vb._context()
+        distributed.bind_to_torch_stream(ctx)
+        for _ in range(PROTOCOL_WARMUP):
+            vb.learning()
+        job.torch.cuda.synchronize()
+        ctx.set_profiling(True)
+        ctx.kernel_time()
+        vb._verbose = True                      # (stream marks around the E-step and M-step spans; the line itself is swallowed)
+        walls, e_span, m_span = [], [], []
+        for _ in range(PROTOCOL_WINDOW):
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                vb.learning()
+            walls.append((time.perf_counter() - t0) * 1e3)
+            e_span.append(ctx.elapsed_ms(0, 1))
+            m_span.append(ctx.elapsed_ms(1, 2))
+        doc_ms, ss_ms, calls = ctx.kernel_time()
+        ctx.set_profiling(False)
+        calls = max(1, calls)
+        doc_ms, ss_ms = doc_ms / calls, ss_ms / calls
+        ldk = ctx_table_stride(ctx)
+        nbytes = V * K * 8                      # what crosses the links: the live K columns of the V x ldk statistics
+        ring = 2.0 * (n - 1) / n * nbytes / (XGMI_LINK_GBPS * 1e9) * 1e3
+        direct = 2.0 * nbytes / n / (XGMI_LINK_GBPS * 1e9) * 1e3
+        step = float(np.mean(walls))
+        predicted = step + ring
+        total_docs = args.extra_docs or 1000000
+        rows.append({"n_gpus_modelled": n, "docs_rank0": len(ptr) - 1, "nnz_rank0": int(ptr[-1]),
+                     "ms_per_step_measured": step, "kernel_ms_documents": doc_ms, "kernel_ms_sstats": ss_ms,
+                     "estep_span_ms": float(np.mean(e_span)), "mstep_span_ms": float(np.mean(m_span)),
+                     "table_prep_ms": float(np.mean(e_span)) - doc_ms - ss_ms,
+                     "host_and_launch_ms": step - float(np.mean(e_span)) - float(np.mean(m_span)),
+                     "allreduce_bytes": nbytes, "table_stride": ldk,
+                     "allreduce_ms_model_ring": ring, "allreduce_ms_model_direct": direct,
+                     "predicted_ms_per_step": predicted, "predicted_docs_per_s": total_docs / (predicted * 1e-3),
+                     "predicted_strong_scaling_efficiency": step_ms_full / (n * predicted)})
+        release(vb)
+        del vb, ctx, wl
+    return {"model": True,
+            "note": "NOT a multi-GPU measurement: rank 0's shard of cfg 4 for N = 2 / 4 / 8 timed on ONE GPU (full K x V "
+                    "tables, nnz-balanced document shard) + a modelled, non-overlapped ring all-reduce of the K x V "
+                    "statistics at %.0f GB/s per xGMI link; efficiency = T(1) / (N * (T_shard(N) + T_allreduce(N)))" % XGMI_LINK_GBPS,
+            "ms_per_step_n1": step_ms_full, "per_n": rows}
+
+
 def ctx_table_stride(ctx):
     return int(ctx._lib.pylda_table_stride(ctx._h))
 
@@ -476,6 +542,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", "--no-ap-extra", dest="no_extras", action="store_true",
                     help="primary record only (no cfg 2 / cfg 4 / cfg 5 sub-records)")
+    ap.add_argument("--no-shard-proxy", action="store_true",
+                    help="skip the single-GPU proxy of the cfg 4 strong-scaling curve (rank 0's shard for N = 2 / 4 / 8 + modelled exchange)")
     ap.add_argument("--extra-docs", type=int, default=None, help="corpus size of the cfg 4 sub-record (smoke runs)")
     ap.add_argument("--variant", type=int, default=-1, help="force a kernel variant (A/B runs)")
     ap.add_argument("--option", action="append", default=[], help="name=value library option (A/B runs)")
@@ -526,6 +594,8 @@ def main():
                 out["synth1m"] = sub
             release(vb4)
             del vb4, ctx4, wl4
+            if job.world == 1 and not args.no_shard_proxy:
+                out["synth1m"]["shard_proxy"] = shard_proxy(job, args, rec4["ms_per_step"])
         except AssertionError:
             raise
         except Exception as exc:

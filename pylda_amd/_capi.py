@@ -163,30 +163,48 @@ class _PinnedBlock(object):
             pass
 
 
-_pinned_pool = {}            # nbytes -> [free pointers]; at most _PINNED_KEEP per size are kept for reuse
-_PINNED_KEEP = 3
+# Idle page-locked blocks, oldest first: (pointer, nbytes).  The pool is bounded by BYTES, not by count per size - a
+# long-running process that asks for many different shapes (inference() on corpora of varying D) must not accumulate
+# page-locked memory - and arrays above _PINNED_MAX_ARRAY (the 2 GB gamma of a 1M-document corpus) are never pinned.
+_pinned_idle = []
+_pinned_idle_bytes = 0
+_PINNED_POOL_CAP = 1 << 30          # idle page-locked bytes kept for reuse (least recently released go first)
+_PINNED_MAX_ARRAY = 1 << 29         # larger arrays come from ordinary (pageable) memory
 
 
 def _pinned_release(ptr, nbytes):
-    free = _pinned_pool.setdefault(nbytes, [])
-    if len(free) < _PINNED_KEEP:
-        free.append(ptr)
-    elif _lib is not None:
-        _lib.pylda_host_free(_vp(ptr))
+    global _pinned_idle_bytes
+    _pinned_idle.append((ptr, nbytes))
+    _pinned_idle_bytes += nbytes
+    while _pinned_idle and _pinned_idle_bytes > _PINNED_POOL_CAP:
+        old_ptr, old_bytes = _pinned_idle.pop(0)
+        _pinned_idle_bytes -= old_bytes
+        if _lib is not None:
+            _lib.pylda_host_free(_vp(old_ptr))
+
+
+def pinned_pool_bytes():
+    """Page-locked bytes currently idle in the pool (for tests and diagnostics)."""
+    return _pinned_idle_bytes
 
 
 def pinned_empty(shape, dtype=np.float64):
     """numpy.empty in page-locked host memory (pylda_host_alloc): the arrays e_step() / m_step() hand back and
-    forth move at the PCIe rate.  Recycled through a small pool - page-locking 50 MB costs milliseconds."""
+    forth move at the PCIe rate.  Recycled through a small pool - page-locking 50 MB costs milliseconds - that is
+    capped at _PINNED_POOL_CAP idle bytes; very large arrays and failed allocations fall back to numpy.empty."""
+    global _pinned_idle_bytes
     lib = load()
     shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
     nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
-    if nbytes == 0:
+    if nbytes == 0 or nbytes > _PINNED_MAX_ARRAY:
         return np.empty(shape, dtype=dtype)
-    free = _pinned_pool.get(nbytes)
-    if free:
-        ptr = free.pop()
-    else:
+    ptr = None
+    for i in range(len(_pinned_idle) - 1, -1, -1):      # most recently released block of exactly this size
+        if _pinned_idle[i][1] == nbytes:
+            ptr = _pinned_idle.pop(i)[0]
+            _pinned_idle_bytes -= nbytes
+            break
+    if ptr is None:
         handle = _vp()
         rc = lib.pylda_host_alloc(nbytes, ctypes.byref(handle))
         if rc != 0:                          # (no page-locked memory left: ordinary memory works everywhere)

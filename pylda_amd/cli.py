@@ -144,8 +144,14 @@ def _launcher_argv(gpus, argv):
 def _join_ranks(opt):
     """(rank, world, device, process group) of a --gpus N run; (0, 1, --device, None) otherwise."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and opt.gpus <= 1:
+        # started under torchrun (or another launcher) without --gpus: WORLD_SIZE ranks that each trained the whole
+        # corpus on --device and wrote the same run directory would be silently wrong - the launcher's size it is
+        opt.gpus = world
     if opt.gpus <= 1 or world <= 1:
         return 0, 1, opt.device, None
+    if opt.gpus != world:
+        raise SystemExit("--gpus %d does not match the launcher's WORLD_SIZE %d" % (opt.gpus, world))
     import torch
     import torch.distributed as dist
     rank = int(os.environ["RANK"])

@@ -5,7 +5,7 @@
 
 #include <string>
 
-namespace pylda {
+namespace pylda __attribute__((visibility("hidden"))) {
 
 int comm_unique_id(void* id_out, std::string* err);
 int comm_init(void** comm, const void* id_bytes, int rank, int world, std::string* err);

@@ -50,4 +50,24 @@ __global__ __launch_bounds__(256) void doc_terms_kernel(EstepParams p, int64_t D
     }
 }
 
+// Profiling: work[0] += sum_d I_d, work[1] += sum_d I_d N_d (inner iterations executed, and their terms) - single
+// workgroup, so the accumulation over E-steps needs no atomics.
+__global__ __launch_bounds__(1024) void work_count_kernel(const int32_t* __restrict__ iters, const int64_t* __restrict__ doc_ptr,
+                                                          int64_t D, double* __restrict__ work)
+{
+    __shared__ double scratch[16];
+    double a = 0.0, b = 0.0;
+    for (int64_t d = threadIdx.x; d < D; d += 1024) {
+        const double it = (double)iters[d];
+        a += it;
+        b += it * (double)(doc_ptr[d + 1] - doc_ptr[d]);
+    }
+    a = block_sum<1024>(a, scratch);
+    b = block_sum<1024>(b, scratch);
+    if (threadIdx.x == 0) {
+        work[0] += a;
+        work[1] += b;
+    }
+}
+
 }  // namespace pylda

@@ -25,37 +25,9 @@
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
+#include "estep_limits.h"
 
 namespace pylda {
-
-// LDS carve (all offsets multiples of 16 bytes, G17):
-struct GenericLds {
-    size_t tile, t, lt, gam, r, lognrm, cts, ids, red, scratch, total;
-};
-
-__host__ __device__ inline GenericLds generic_lds_layout(int K, int n_cap, int tile_stride,
-                                                          int nthreads, bool tile_global)
-{
-    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    GenericLds L;
-    size_t off = 0;
-    L.tile = off;   off = a16(off + (tile_global ? 0 : (size_t)n_cap * tile_stride * 8));
-    L.t = off;      off = a16(off + (size_t)K * 8);
-    L.lt = off;     off = a16(off + (size_t)K * 8);
-    L.gam = off;    off = a16(off + (size_t)K * 8);
-    L.r = off;      off = a16(off + (size_t)n_cap * 8);
-    L.lognrm = off; off = a16(off + (size_t)n_cap * 8);
-    L.cts = off;    off = a16(off + (size_t)n_cap * 8);
-    L.ids = off;    off = a16(off + (size_t)n_cap * 4);
-    // cross-group partials of pass 2: G x K doubles, G = nthreads / KL <= nthreads / min(K', nthreads)
-    int kl = 1;
-    while (kl < K && kl < nthreads) kl <<= 1;
-    int groups = nthreads / kl;
-    L.red = off;    off = a16(off + (size_t)groups * K * 8);
-    L.scratch = off; off = a16(off + (size_t)(nthreads / 64) * 8);
-    L.total = off;
-    return L;
-}
 
 template <int NT, int MODE>
 __global__ __launch_bounds__(NT) void estep_generic_kernel(EstepParams p)

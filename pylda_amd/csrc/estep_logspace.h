@@ -15,15 +15,10 @@
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
+#include "estep_limits.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace pylda {
-
-__host__ __device__ inline size_t logspace_lds_bytes(int K)
-{
-    // psi[K], gam[K], gacc[4][K], scratch[4]
-    return (size_t)(6 * K + 4) * 8 + 64;
-}
 
 __device__ inline void logspace_document(const EstepParams& p, const double* __restrict__ elog_wk,
                                          double* __restrict__ sstats_extra, int doc, char* smem)

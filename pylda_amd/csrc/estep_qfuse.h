@@ -26,13 +26,10 @@
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
+#include "estep_limits.h"
 
 namespace pylda {
 
-#ifndef PYLDA_QF_SLOTS
-#define PYLDA_QF_SLOTS 128
-#endif
-constexpr int kQfMaxSlots = PYLDA_QF_SLOTS;   // word slots per wavefront: documents up to 1024 distinct terms
 
 template <int NP, int TWL>
 struct QfuseLds {

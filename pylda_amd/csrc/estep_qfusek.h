@@ -17,6 +17,7 @@
 #include "estep_common.h"
 #include "estep_qfuse.h"
 #include "special_device.h"
+#include "estep_limits.h"
 
 namespace pylda {
 

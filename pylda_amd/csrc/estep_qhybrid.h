@@ -19,11 +19,11 @@
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
+#include "estep_limits.h"
 
 namespace pylda {
 
 constexpr int kQhSpan = 16;                 // tier L/S words whose normalisers are finished together (>= 4*RWL)
-constexpr int kQhMaxTail = 96;              // tier L + S words per wavefront (8 waves: 768 words)
 
 template <int W, int KRL, int RWL>
 struct QhybridLds {

@@ -40,39 +40,15 @@
 
 namespace pylda {
 
-#ifndef PYLDA_QUAD_FORCE_PRE
-#define PYLDA_QUAD_FORCE_PRE 0
-#endif
-#ifndef PYLDA_QUAD_FORCE_GCNT
-#define PYLDA_QUAD_FORCE_GCNT 0
-#endif
-// Development builds only (tools/phase_stamps_quad.py): s_memtime stamps around the phases of the inner
-// loop, summed per wavefront and written over the document's gamma row.  The stamps drain the LDS queue,
-// so absolute times are 10-15 % high; the split between the phases is what counts.
-#ifndef PYLDA_QUAD_STAMPS
-#define PYLDA_QUAD_STAMPS 0
-#endif
-// Timing probes with UNCHANGED results (development builds, tools/ab_build.py): what a longer serial chain costs in
-// situ, as a bound on what shortening it could gain.  C2: the gamma phase's exp(psi(gamma) - c) evaluated twice in a
-// row (the second argument is gamma + 0 * first result).  T2: the second normaliser transpose read, written back and
-// read again (one more LDS round trip on the chain).
-#ifndef PYLDA_QUAD_PROBE_C2
-#define PYLDA_QUAD_PROBE_C2 0
-#endif
-#ifndef PYLDA_QUAD_PROBE_T2
-#define PYLDA_QUAD_PROBE_T2 0
-#endif
-#if PYLDA_QUAD_STAMPS
-#define QUAD_STAMP(j)                                                          \
-    do {                                                                       \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
-        const long long now_ = __builtin_amdgcn_s_memtime();                   \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
-        stamp_acc[j] += now_ - stamp_prev;                                     \
-        stamp_prev = now_;                                                     \
-    } while (0)
+// Development builds only (tools/phase_stamps_quad.py compiles a copy with -DPYLDA_QUAD_STAMPS=1): s_memtime stamps
+// around the phases of the inner loop; the instrumentation itself lives in tools/quad_stamps.h.
+#if defined(PYLDA_QUAD_STAMPS) && PYLDA_QUAD_STAMPS
+#include "../../tools/quad_stamps.h"
 #else
+#define PYLDA_QUAD_STAMPS 0
 #define QUAD_STAMP(j) do { } while (0)
+#define QUAD_STAMPS_BEGIN() do { } while (0)
+#define QUAD_STAMPS_DUMP() do { } while (0)
 #endif
 
 template <int TL, int RWL, int TWL>
@@ -84,7 +60,7 @@ struct QuadLds {
     // DPP level, 3 instructions per word) so that it takes half the LDS - which, with the word counts
     // re-read from global memory, is what lets 64 rows fit beside it (stride 256: 128 KiB in one
     // workgroup's 160 KiB; stride 128: 64 KiB in each of two workgroups' 80 KiB).
-    static constexpr bool kPre = TWL >= 4 || (TL == 32 && PYLDA_QUAD_FORCE_PRE);
+    static constexpr bool kPre = TWL >= 4;
     static constexpr int kPartials = kPre ? TL / 2 : TL;                           // partial sums per word in the transpose
     static constexpr int kRedStride = kPartials == 8 ? 10 : kPartials == 16 ? 20 : 40;   // 16-byte aligned rows, b128 read-back (QuiltLds / QwideLds)
     static constexpr size_t red_wave = (size_t)G * 8 * kRedStride * 8;             // 5120 B (kPre: 2560 B)
@@ -96,7 +72,7 @@ struct QuadLds {
     static constexpr size_t alf = misc + (size_t)8 * W * 8;                        // [kTopics] alpha (1 beyond K)
     static constexpr size_t gpv = alf + (size_t)kTopics * 8;                       // [kTopics] gamma before the last update
     static constexpr size_t cnt = gpv + (size_t)kTopics * 8;                       // double [2][W * 64] counts of the words a lane finishes
-    static constexpr bool kGlobalCounts = TWL >= 4 || PYLDA_QUAD_FORCE_GCNT;
+    static constexpr bool kGlobalCounts = TWL >= 4;
     static constexpr size_t rows = (cnt + (kGlobalCounts ? 0 : (size_t)2 * W * 64 * 8) + 255) & ~(size_t)255;   // [16][TWL][kTopics]
     static constexpr size_t total = rows + (size_t)16 * TWL * kTopics * 8;
     static_assert(TL != 16 || 2 * total <= 160 * 1024, "K <= 128: two workgroups per CU");
@@ -134,11 +110,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     double* gpv = reinterpret_cast<double*>(smem + L::gpv);
     double* cntv = reinterpret_cast<double*>(smem + L::cnt);    // (as doubles: no int -> fp64 conversion per iteration)
 
-#if PYLDA_QUAD_STAMPS
-    long long stamp_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long stamp_prev = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
+    QUAD_STAMPS_BEGIN();
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -364,14 +336,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             double2 h1[NPIECE];
 #pragma unroll
             for (int x = 0; x < NPIECE; ++x) h1[x] = mysrc[FL * x];
-#if PYLDA_QUAD_PROBE_T2
-            wave_lds_exchange();
-#pragma unroll
-            for (int x = 0; x < NPIECE; ++x) const_cast<double2*>(mysrc)[FL * x] = h1[x];
-            wave_lds_exchange();
-#pragma unroll
-            for (int x = 0; x < NPIECE; ++x) h1[x] = mysrc[FL * x];
-#endif
             const double cnt1 = count_of(1);
             // the reciprocal chain of the first chunk runs while the second transpose is in flight; the second
             // chunk's chain is placed behind the first 32 FMAs of pass B (which need r0 only)
@@ -482,12 +446,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
             QUAD_STAMP(11);                                               // gamma update, change into the fixed-point sum
-#if PYLDA_QUAD_PROBE_C2
-            const double t_probe = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
-            const double t_next = exp_digamma_minus_levels<true>(fma(t_probe, 0.0, gam), psi_total, coef_a, &coef_b);
-#else
             const double t_next = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
-#endif
             QUAD_STAMP(12);                                               // exp(psi(gamma) - psi(sum))
             tt[(buf ^ 1) * KT + ktid] = topic_live ? t_next : 0.0;
             if (ktid == 0) store_u64_hi(&chg[buf ^ 1], 0u);
@@ -588,21 +547,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     } else if (topic_thread && !p.heldout) {
         p.tfinal[(size_t)doc * ldk + ktid] = 0.0;
     }
-#if PYLDA_QUAD_STAMPS
-    QUAD_STAMP(10);                                                       // epilogue up to the reductions
-    if (lane == 0) {
-        unsigned hw_id, lds_alloc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc));
-        double* dbg = p.gamma + (size_t)doc * K + wave * 16;              // (needs K >= 16 * wavefronts)
-        for (int j = 0; j < 11; ++j) dbg[j] = (double)stamp_acc[j];
-        dbg[11] = (double)it;
-        dbg[12] = (double)hw_id;
-        dbg[13] = (double)lds_alloc;
-        dbg[14] = (double)stamp_acc[11];
-        dbg[15] = (double)stamp_acc[12];
-    }
-#endif
+    QUAD_STAMPS_DUMP();                                                   // (development builds: epilogue stamp, per-wavefront sums over the gamma row)
     term1 = wave_sum(term1);
     term2 = wave_sum(term2);
     lse_term = wave_sum(lse_term);

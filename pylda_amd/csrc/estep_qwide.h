@@ -31,11 +31,10 @@
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
+#include "estep_limits.h"
 
 namespace pylda {
 
-constexpr int kQwMaxTail = 64;              // tier L + S words per wavefront (8 waves: 512 words)
-constexpr int kQwRegWords = 128;            // tier R words per document (8 waves x 2 groups x 8)
 
 template <int W, int JJ>
 struct QwideLds {

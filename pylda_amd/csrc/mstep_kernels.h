@@ -2,6 +2,7 @@
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
+#include "estep_limits.h"
 
 namespace pylda {
 
@@ -154,13 +155,6 @@ __global__ __launch_bounds__(256) void outer_pack_kernel(const double* __restric
 //   io[0 .. K)      alpha: in, and out (also written to `alpha_device`, what the next E-step reads)
 //   stats[0 .. K)   alpha sufficient statistics (:232-233), summed over the ranks;  docs: #documents (ditto)
 //   work            4 K scratch doubles
-struct NewtonParams {
-    int iterations;             // hyper_parameter_iteration (100)
-    int maximum_decay;          // hyper_parameter_maximum_decay (10)
-    double threshold;           // hyper_parameter_converge_threshold (1e-6)
-    double decay_power[17];     // numpy.power(hyper_parameter_decay_factor, d), d = 0 .. maximum_decay (computed by the host's pow)
-};
-
 __global__ __launch_bounds__(1024) void alpha_newton_kernel(double* __restrict__ io, const double* __restrict__ stats,
                                                             const double* __restrict__ docs_ptr, int K, NewtonParams np,
                                                             double* __restrict__ work, double* __restrict__ alpha_device)
@@ -226,26 +220,6 @@ __global__ __launch_bounds__(1024) void alpha_newton_kernel(double* __restrict__
     for (int k = tid; k < K; k += 1024) {
         io[k] = alpha[k];
         alpha_device[k] = alpha[k];
-    }
-}
-
-// Profiling: work[0] += sum_d I_d, work[1] += sum_d I_d N_d (inner iterations executed, and their terms) - single
-// workgroup, so the accumulation over E-steps needs no atomics.
-__global__ __launch_bounds__(1024) void work_count_kernel(const int32_t* __restrict__ iters, const int64_t* __restrict__ doc_ptr,
-                                                          int64_t D, double* __restrict__ work)
-{
-    __shared__ double scratch[16];
-    double a = 0.0, b = 0.0;
-    for (int64_t d = threadIdx.x; d < D; d += 1024) {
-        const double it = (double)iters[d];
-        a += it;
-        b += it * (double)(doc_ptr[d + 1] - doc_ptr[d]);
-    }
-    a = block_sum<1024>(a, scratch);
-    b = block_sum<1024>(b, scratch);
-    if (threadIdx.x == 0) {
-        work[0] += a;
-        work[1] += b;
     }
 }
 

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace pylda {
+namespace pylda __attribute__((visibility("hidden"))) {
 
 // For every word the (document, CSR position) pairs of its occurrences, in document order:
 //   post_pos[i]  position in the corpus' CSR arrays, grouped by term id (stable: document order inside a term);

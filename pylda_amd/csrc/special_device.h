@@ -5,7 +5,7 @@
 // variational_bayes.py:195,197.  They are re-derived here from the published
 // definitions (upward recurrence + Bernoulli asymptotic series); arguments on
 // this path are always > 0 (alpha > 0, eta >= beta > 0), so there is no
-// reflection branch.  Pinned against scipy samples in tests/test_gpu_special.py.
+// reflection branch.  Pinned against scipy samples (tests/golden/special_fn.npz) by tests/test_gpu_estep.py::test_device_special_functions.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void sstats_gather_kernel(
 // segment, so each posting's t_d row is one contiguous ldk*8-byte read and the posting index is
 // loaded once instead of once per 64-topic chunk.
 //
-// Document-blocked mode (exec_order != nullptr; capi.hip build_postings).  A term's postings are in document
+// Document-blocked mode (exec_order != nullptr; sstats_gather.hip build_postings).  A term's postings are in document
 // order, so cutting its segments at the boundaries of NB contiguous document blocks costs nothing - and a block's
 // t rows (<= 3.3 MB) fit one XCD's 4 MB L2.  Workgroups are dispatched round-robin over the 8 XCDs, so workgroup g
 // takes its four segments from the list of XCD g % 8, which holds the segments of blocks g % 8, g % 8 + 8, ...

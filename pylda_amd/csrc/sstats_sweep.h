@@ -41,6 +41,7 @@
 namespace pylda {
 
 constexpr int kSweepSegment = 64;
+constexpr int kSweepCounters = 8;        // rendezvous counters: one per XCD (workgroups are dealt to the XCDs round-robin)
 
 struct SweepParams {
     const int64_t* seg_begin;       // segments of the postings, cut at document-block boundaries, in term order
@@ -58,7 +59,8 @@ struct SweepParams {
     const int32_t* term_of;         // [passes][wavefronts][T]: owned terms, -1 = none
     int passes;
     int NB;
-    unsigned* rendezvous;           // zeroed before the launch
+    unsigned* rendezvous;           // kSweepCounters counters, 32 words apart, zeroed before the launch
+    int per_xcd;                    // 1: the workgroups of an XCD meet among themselves (the L2 they share is what the pacing is for)
     unsigned spin_limit;
 };
 
@@ -174,7 +176,15 @@ __global__ __launch_bounds__(kWave* WPB) void sstats_sweep_kernel(SweepParams p)
             }
             if (b + 1 < p.NB || pass + 1 < p.passes) {
                 ++meet;
-                sweep_rendezvous(p.rendezvous, meet * gridDim.x, p.spin_limit);
+                if (p.per_xcd) {
+                    // workgroup g runs on XCD g % 8: only those 32 share an L2, so only they need to walk the blocks
+                    // together - a rendezvous of 32 has less arrival skew than one of 256, and the XCDs may drift
+                    const unsigned xcd = blockIdx.x % kSweepCounters;
+                    const unsigned members = (gridDim.x + kSweepCounters - 1 - xcd) / kSweepCounters;
+                    sweep_rendezvous(p.rendezvous + 32 * xcd, meet * members, p.spin_limit);
+                } else {
+                    sweep_rendezvous(p.rendezvous, meet * gridDim.x, p.spin_limit);
+                }
             }
         }
         // the finalize pass for the owned terms: sstats = B * acc, and the corpus entropy term the document kernels

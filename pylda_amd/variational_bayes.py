@@ -285,8 +285,12 @@ class VariationalBayes(Inferencer):
             self._counter % self._hyper_parameter_optimize_interval == 0
         # the alpha update (optimize_hyperparameters, :277-324, with the reference's defaults) runs on the device
         # behind the sum over the ranks, unless a subclass replaced the method or _device_alpha_update is cleared
+        # (a method patched on the INSTANCE counts as a replacement too; and the device update divides by the corpus'
+        # document count, so a caller who changed _number_of_documents gets the host form, which honours it)
         on_device = update_alpha and self.__dict__.get("_device_alpha_update", True) and \
-            type(self).optimize_hyperparameters is VariationalBayes.optimize_hyperparameters
+            type(self).optimize_hyperparameters is VariationalBayes.optimize_hyperparameters and \
+            "optimize_hyperparameters" not in self.__dict__ and \
+            (group is not None or self._number_of_documents == corpus.D)
         ctx.mstep_enqueue(corpus, self._alpha_beta, hyper_parameter_iteration=100 if on_device else 0)
         if group is not None:
             distributed.allreduce_outer(ctx, group)
@@ -300,8 +304,9 @@ class VariationalBayes(Inferencer):
         if on_device:
             self._alpha_alpha = alpha
         elif update_alpha:
+            # (one rank: the reference's own count, self._number_of_documents, :279; several: the sum over the ranks)
             self.optimize_hyperparameters(alpha_sufficient_statistics,
-                                          number_of_documents=number_of_documents)
+                                          number_of_documents=number_of_documents if group is not None else None)
         clock_m_step = time.time() - clock_m_step + (ctx.elapsed_ms(1, 2) * 1e-3 if timed else 0.0)
 
         joint_log_likelihood = document_log_likelihood + topic_log_likelihood

@@ -519,7 +519,7 @@ def test_iteration_cap_and_threshold_on_register_kernels(capi, K, V, mean_len):
     eta = rng.gamma(100.0, 0.01, (K, V))
     alpha = rng.uniform(0.05, 1.0, K)
     # (7, 0.0), (5, -1.0), (9, 1e-13), (50, 2000.0): outside the fixed-point stop test's range - the library
-    # routes those E-steps to the kernels that compare in floating point (capi.hip choose_variant)
+    # routes those E-steps to the kernels that compare in floating point (plan.hip choose_variant)
     for mi, tol in [(1, 1e-6), (2, 1e-6), (50, 1e-1), (7, 0.0), (5, -1.0), (50, 1e-3), (9, 1e-13), (50, 2000.0)]:
         ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
         out = run(capi, alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)

@@ -120,3 +120,61 @@ def test_oracle_spot_check_on_full_size_run(cfg3):
         assert np.array_equal(ref["iters"], c["iters"][docs]), (name, ref["iters"], c["iters"][docs])
         assert rel_err(c["gamma"][docs], ref["gamma"]) < 1e-9, name
         assert rel_err(c["doc_ll"][docs], ref["doc_ll"]) < 1e-9, name      # (the stated bar is 1e-5)
+
+
+def test_oracle_check_of_full_size_statistics(cfg3):
+    """sstats[:, w] of the FULL-size run (variational_bayes.py:207) against the oracle for terms whose every posting
+    the oracle can afford: ~20 terms with 5..50 postings each - the oracle runs exactly the documents that contain
+    them, so its column w is the complete corpus sum - plus the single most frequent term on a contiguous document
+    shard run through the same context.  cfg 3 takes the dispatch-paced, document-blocked gather, cfg 4 the
+    persistent sweep (3 passes): a wrong-but-conserving accumulation would pass the invariants above, not this."""
+    from oracle import c_oracle
+    from conftest import csr_slice
+    c, ctx = cfg3, cfg3["ctx"]
+    postings = np.bincount(c["ids"], minlength=c["V"])
+    rng = np.random.default_rng(7)
+    budget = 600 if c["K"] <= 128 else 300                 # documents the C oracle gets (seconds, not minutes)
+    pool = np.nonzero((postings >= 5) & (postings <= 50))[0]
+    assert pool.size >= 40
+    cand = rng.choice(pool, 40, replace=False)
+    pos = np.nonzero(np.isin(c["ids"], cand))[0]           # one pass over the corpus for all candidates
+    pos_term = c["ids"][pos]
+    pos_doc = np.searchsorted(c["ptr"], pos, side="right") - 1
+    terms, docs = [], np.zeros(0, np.int64)
+    for w in cand:
+        d = pos_doc[pos_term == w]
+        assert d.size == postings[w]
+        merged = np.union1d(docs, d)
+        if merged.size > budget:
+            continue
+        terms.append(int(w))
+        docs = merged
+        if len(terms) == 20:
+            break
+    assert len(terms) >= 10, (len(terms), docs.size)
+    ptr, tid, tct = csr_slice(c["ptr"], c["ids"], c["cts"], docs)
+    ref = c_oracle.e_step(c["alpha"], c["eta"], ptr, tid, tct)
+    assert np.array_equal(ref["iters"], c["iters"][docs])
+    got, want = c["sstats"][:, terms], ref["sstats"][:, terms]
+    assert np.max(np.abs(got - want)) < 1e-8, np.max(np.abs(got - want))
+    assert np.all(want.sum(axis=0) > 0)
+    print("%s: %d terms (%d..%d postings) on %d documents, max |sstats - oracle| %.2e"
+          % (c["name"], len(terms), postings[terms].min(), postings[terms].max(), docs.size, np.max(np.abs(got - want))))
+    # the most frequent term, on a contiguous shard the oracle can run completely
+    top = int(np.argmax(postings))
+    n_shard = 1200 if c["K"] <= 128 else 600
+    lo = int(rng.integers(0, c["D"] - n_shard))
+    sel = np.arange(lo, lo + n_shard)
+    sp, si, sc = csr_slice(c["ptr"], c["ids"], c["cts"], sel)
+    shard = ctx.corpus(sp, si, sc)
+    ctx.estep(shard)
+    shard_stats = ctx.get_sstats()
+    shard.close()
+    sref = c_oracle.e_step(c["alpha"], c["eta"], sp, si, sc)
+    in_shard = int((si == top).sum())
+    assert in_shard >= 5, in_shard
+    assert np.max(np.abs(shard_stats[:, top] - sref["sstats"][:, top])) < 1e-8
+    assert np.max(np.abs(shard_stats - sref["sstats"])) < 1e-8
+    # restore the fixture's state for the tests that follow (the context's statistics are those of the last E-step)
+    ctx.estep(c["corpus"])
+    assert np.array_equal(ctx.get_sstats(), c["sstats"])

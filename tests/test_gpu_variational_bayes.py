@@ -309,3 +309,26 @@ def test_alpha_update_on_the_device(ap_train, K, docs, seed):
     assert np.all(got > 0) and rel_err(got, want) < 1e-10, (got[:4], want[:4])
     if seed == 1:
         assert rel_err(got, ap_train["alpha_after"]) < 1e-10
+
+
+def test_pinned_pool_is_bounded_by_bytes():
+    """the page-locked pool behind e_step() / get_gamma() must not grow with the number of distinct
+    shapes a long-running process asks for; very large arrays are not pinned at all."""
+    from pylda_amd import _capi
+    _capi.load()
+    cap, big = _capi._PINNED_POOL_CAP, _capi._PINNED_MAX_ARRAY
+    try:
+        _capi._PINNED_POOL_CAP, _capi._PINNED_MAX_ARRAY = 4 << 20, 2 << 20
+        for n in range(1, 200):                               # 199 different sizes, 8 KB .. 1.6 MB
+            a = _capi.pinned_empty((n, 1024))
+            a[:] = n
+            assert a.sum() == n * n * 1024
+            del a
+            assert _capi.pinned_pool_bytes() <= _capi._PINNED_POOL_CAP
+        assert _capi.pinned_pool_bytes() > 0                  # recent blocks are kept for reuse
+        before = _capi.pinned_pool_bytes()
+        b = _capi.pinned_empty((300, 1024))                   # 2.4 MB > _PINNED_MAX_ARRAY: ordinary memory
+        del b
+        assert _capi.pinned_pool_bytes() == before
+    finally:
+        _capi._PINNED_POOL_CAP, _capi._PINNED_MAX_ARRAY = cap, big

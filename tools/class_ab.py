@@ -1,7 +1,7 @@
 """A/B of kernel classes on slices of the cfg-3 / cfg-4 corpus: python tools/class_ab.py cfg3 nmin nmax name=value ..."""
-import sys, time, json
+import sys, time, json, os
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pylda_amd import _capi
 from pylda_amd.corpus import synthetic_lda_shard
 cfg, nmin, nmax = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])

@@ -17,6 +17,8 @@ shutil.rmtree(dst, ignore_errors=True)
 os.makedirs(dst)
 for d in ("pylda_amd", "include"):
     shutil.copytree(os.path.join(root, d), os.path.join(dst, d), ignore=shutil.ignore_patterns("lib", "__pycache__"))
+os.makedirs(os.path.join(dst, "tools"))
+shutil.copy(os.path.join(root, "tools", "quad_stamps.h"), os.path.join(dst, "tools", "quad_stamps.h"))   # estep_quad.h includes it under -DPYLDA_QUAD_STAMPS=1
 open(os.path.join(dst, "run_dbg.py"), "w").write('''
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
