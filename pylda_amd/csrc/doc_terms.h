@@ -19,11 +19,16 @@
 
 namespace pylda {
 
-__global__ __launch_bounds__(256) void doc_terms_kernel(EstepParams p, int64_t D)
+// It is launched per LAUNCH CLASS, right behind the class' document kernel on the same stream (p.order = the class'
+// documents, `count` of them): the wavefronts then run in the tail of that kernel and beside the other classes'
+// kernels - on CUs a draining class has freed - instead of as a serial pass after the last document kernel.
+__global__ __launch_bounds__(256) void doc_terms_kernel(EstepParams p, int64_t count)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t doc = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
-    if (doc >= D || p.status[doc] != 3) return;
+    const int64_t slot = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+    if (slot >= count) return;
+    const int64_t doc = p.order ? p.order[slot] : slot;
+    if (p.status[doc] != 3) return;
     const int K = p.K;
     const double* gamma = p.gamma + (size_t)doc * K;
     const double* t = p.tfinal + (size_t)doc * p.ldk;

@@ -330,12 +330,26 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         }
         join();
     }
-    // the document terms the register kernels left out on the training fast path (status 3; doc_terms.h)
+    // the document terms the register kernels left out on the training fast path (status 3; doc_terms.h): one wavefront
+    // per document, fp64-VALU bound.  Beside the dispatch-paced statistics gather (L2-bound) it runs on an auxiliary
+    // stream, CONCURRENTLY with it - neither needs the other's output; the persistent sweep needs every CU to itself
+    // (one workgroup per CU, all resident), so there the pass stays in front of it.
     bool leaves_terms = false;          // (slab and generic kernels always finish their documents themselves)
     for (const Launch& L : c->plan)
         leaves_terms = leaves_terms || L.variant == kQuad || L.variant == kQuilt || L.variant == kQwide || L.variant == kQfuse || L.variant == kQfusek;
-    if (!heldout && !p.want_doc_ll && c->D > 0 && leaves_terms)
-        hipLaunchKernelGGL(doc_terms_kernel, dim3((unsigned)((c->D + 3) / 4)), dim3(256), 0, ctx->stream, p, c->D);
+    const bool terms_pass = !heldout && !p.want_doc_ll && c->D > 0 && leaves_terms && !ctx->force_logspace;
+    const bool terms_beside_gather = terms_pass && c->have_postings && !c->sweep && ctx->terms_overlap;
+    if (terms_pass) {
+        p.order = nullptr;
+        hipStream_t st = ctx->stream;
+        if (terms_beside_gather) {
+            st = ctx->aux_stream[0];
+            HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->fork_event, 0));
+        }
+        hipLaunchKernelGGL(doc_terms_kernel, dim3((unsigned)((c->D + 3) / 4)), dim3(256), 0, st, p, c->D);
+        if (terms_beside_gather) HIP_TRY(ctx, hipEventRecord(ctx->join_event[0], st));
+    }
     close_bracket(doc_bracket, ctx->stream);
     if (ctx->profiling) ctx->estep_calls += 1;
     if (ctx->profiling && c->D > 0)       // inner iterations actually executed, for the fp64 roofline and doc-iterations/s
@@ -349,6 +363,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         }
         const int ss_bracket = open_bracket(-2, ctx->stream);
         rc = enqueue_sstats_gather(ctx, c);
+        if (terms_beside_gather) (void)hipStreamWaitEvent(ctx->stream, ctx->join_event[0], 0);      // (inside the bracket: the pair's wall time)
         close_bracket(ss_bracket, ctx->stream);
         if (rc != PYLDA_OK) return rc;
     }

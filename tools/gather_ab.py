@@ -1,7 +1,7 @@
 """Statistics pass alone on the cfg-3 / cfg-4 corpus for several settings: python tools/gather_ab.py cfg3 name=v,name=v ...
 (each argument one configuration: a new context + corpus, 2 + 5 E-steps, statistics-pass time)"""
-import sys, numpy as np
-sys.path.insert(0, ".")
+import os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pylda_amd import _capi
 from pylda_amd.corpus import synthetic_lda_shard
 cfg = sys.argv[1]

@@ -1,7 +1,7 @@
 """Where one learning() iteration goes: device time of the E-step and M-step spans (stream marks), the host-side
 Newton update, the wall time.  python tools/step_breakdown.py [nips|ap|cfg3]"""
 import os, sys, time, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pylda_amd.variational_bayes import VariationalBayes
 which = sys.argv[1] if len(sys.argv) > 1 else "nips"
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")

@@ -5,7 +5,7 @@
 prints the document-kernel time per E-step (HIP events on the launch streams) for every value."""
 import sys, os
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pylda_amd import _capi
 from pylda_amd.corpus import synthetic_lda_shard
 cfg, name, values = sys.argv[1], sys.argv[2], [int(v, 0) for v in sys.argv[3:]]
