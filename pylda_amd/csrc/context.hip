@@ -228,6 +228,8 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         ctx->gather_sweep = (int)std::min<int64_t>(2, std::max<int64_t>(0, value));
     } else if (!strcmp(name, "gather_round_mb")) {   // (takes effect for corpora whose postings are built afterwards)
         ctx->gather_round_mb = (int)std::max<int64_t>(0, value);
+    } else if (!strcmp(name, "launch_order")) {
+        ctx->launch_order = (int)value;
     } else if (!strcmp(name, "terms_overlap")) {
         ctx->terms_overlap = value != 0;
     } else if (!strcmp(name, "slab_uber")) {

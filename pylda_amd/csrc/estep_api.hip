@@ -287,10 +287,16 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
                 if (hipEventRecord(ctx->join_event[i], ctx->aux_stream[i]) == hipSuccess)
                     (void)hipStreamWaitEvent(main_stream, ctx->join_event[i], 0);
         };
+        // launch order over the classes (the plan lists them longest documents first): option launch_order 1 sends the
+        // classes with the FEWEST documents first, so that the kernels that end the E-step are the large ones
+        std::vector<size_t> launch_seq(separate);
+        std::iota(launch_seq.begin(), launch_seq.end(), (size_t)0);
+        if (ctx->launch_order == 1)
+            std::stable_sort(launch_seq.begin(), launch_seq.end(), [&](size_t a, size_t b) { return c->plan[a].count < c->plan[b].count; });
         size_t launch_index = 0;
-        for (const Launch& L : c->plan) {
-            const int slot = (int)launch_index;
-            if (launch_index >= separate) break;
+        for (const size_t plan_index : launch_seq) {
+            const Launch& L = c->plan[plan_index];
+            const int slot = (int)plan_index;
             if (fan_out) ctx->stream = ctx->aux_stream[launch_index % pylda_ctx::kAux];
             ++launch_index;
             p.order = c->d_order + L.first;

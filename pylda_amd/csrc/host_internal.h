@@ -131,6 +131,7 @@ struct pylda_ctx {
     int gather_sweep = 1;           // the persistent sweep (sstats_sweep.h) at stride 128 / 256: 0 never, 1 when the partial rows of the
                                     // dispatch-paced gather would exceed their budget (rounds), 2 whenever the gather is blocked
     int gather_round_mb = 0;        // budget of the gather's partial rows per round, MiB (0: 4 GiB)
+    int launch_order = 1;           // 0: launch classes in plan order (longest documents first), 1: fewest documents first (cfg 3: -0.5 %)
     int terms_overlap = 1;          // doc_terms_kernel on an auxiliary stream beside the dispatch-paced statistics gather
     int slab_uber = 1;              // small corpora: all slab launch classes in one dispatch
     int wide_postings = 0;          // test hook: 64-bit CSR positions in the postings whatever nnz (automatic from 2^31 pairs)
