@@ -469,6 +469,25 @@ def test_statistics_gather_as_a_persistent_sweep(capi, ap_train, K, blocks, wide
     assert np.max(np.abs(got[1][0][0] - ref["sstats"])) < SSTATS_ATOL
     assert abs(got[1][0][0].sum() - tct.sum()) < 1e-7
     assert np.array_equal(got[1][0][0], got[1][1][0]) and got[1][0][1] == got[1][1][1]
+    # pacing and scheduling options change WHEN things run, never a bit of the result: the sweep's rendezvous per XCD or
+    # chip-wide, the document-terms pass beside the gather or in front of it, the launch order of the classes
+    for options in ([("gather_sweep", 2), ("sweep_xcd", 0)], [("terms_overlap", 0)], [("launch_order", 0)],
+                    [("terms_overlap", 0), ("launch_order", 0), ("gather_sweep", 2), ("sweep_xcd", 0)]):
+        ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_blocks", blocks)
+        ctx.set_option("wide_postings", wide)
+        for name, value in options:
+            ctx.set_option(name, value)
+        corpus = ctx.corpus(ptr, tid, tct)
+        ctx.set_alpha(alpha)
+        ctx.set_eta(eta)
+        ctx.set_option("doc_values", 0)
+        ctx.estep(corpus)
+        fast = ctx.estep_results(corpus)[0]
+        want = got[1][0] if ("gather_sweep", 2) in options else got[0][0]
+        assert np.array_equal(ctx.get_sstats(), want[0]) and fast == want[1], options
+        corpus.close()
+        ctx.close()
 
 
 def test_runs_on_the_system_hip_runtime_without_torch():
