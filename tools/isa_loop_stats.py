@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction mix of a kernel's basic blocks from hipcc -S output.
 
-    python tools/isa_loop_stats.py capi.s <mangled-kernel-name-substring> [--blocks]
+    python tools/isa_loop_stats.py launch_quad.s <mangled-kernel-name-substring> [--blocks]      (hipcc -S --cuda-device-only of the translation unit that instantiates the kernel)
 
 Prints, per basic block of the kernel (label .LBBn_m), the instruction count by class
 (fp64 FMA/MUL/ADD, other VALU, DPP moves, permlane, DS, VMEM, SALU, waitcnt/barrier), so the

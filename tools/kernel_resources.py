@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Registers / scratch per kernel from `hipcc -S --cuda-device-only` output: python tools/kernel_resources.py capi.s [filter]"""
+"""Registers / scratch per kernel from `hipcc -S --cuda-device-only` output: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -S --cuda-device-only -o launch_quad.s pylda_amd/csrc/launch_quad.hip; python tools/kernel_resources.py launch_quad.s [filter]"""
 import re, subprocess, sys
 lines = open(sys.argv[1]).read().splitlines()
 flt = sys.argv[2] if len(sys.argv) > 2 else "estep"
