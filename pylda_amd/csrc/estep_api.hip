@@ -263,11 +263,8 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     if (ctx->profiling && ctx->class_ms.size() != c->plan.size()) ctx->class_ms.assign(c->plan.size(), 0.0);
     const int doc_bracket = open_bracket(-1, ctx->stream);
     if (ctx->force_logspace) {
-        // test hook: mark every document for the log-space kernel
-        std::vector<int32_t> ones((size_t)c->D, 1);
-        HIP_TRY(ctx, hipMemcpyAsync(c->d_status, ones.data(), (size_t)c->D * sizeof(int32_t),
-                                    hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // test hook: mark every document for the log-space kernel (a device fill: no host buffer, no wait)
+        HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_status), 1, (size_t)c->D, ctx->stream));
     } else {
         hipStream_t main_stream = ctx->stream;
         // a small corpus' slab classes go out as one dispatch on the main stream (no fork / join at all when that is
