@@ -280,6 +280,12 @@ int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
  *   "gather_round_mb" budget of the gather's partial rows (one per (term, document block) pair) in MiB, 0 = 4 GiB:
  *                    beyond it the gather runs in rounds over term ranges that reuse the rows;
  *   "wide_postings"  1: 64-bit CSR positions in the postings whatever the corpus size (automatic from 2^31 pairs);
+ *   "sweep_xcd"      1 (default): the sweep's rendezvous per XCD (the 32 workgroups that share an L2), 0: chip-wide;
+ *   "sweep_spin"     polls of a rendezvous before a workgroup goes on alone (pacing only, never correctness);
+ *   "terms_overlap"  1 (default): the document-terms pass of the training fast path runs on an auxiliary stream beside
+ *                    the dispatch-paced statistics gather, 0: in front of it;
+ *   "launch_order"   1 (default): launch classes with the fewest documents go out first, 0: longest documents first
+ *                    (scheduling options never change a bit of the results);
  *   "slab_uber"      1 (default): the slab launch classes of a small corpus go out as one dispatch;
  *   "quad" (1: documents of <= 224 distinct terms at 64 < K <= 256 run on the quad kernel), "quilt_odd",
  *   "quilt12", "lds_pad"  A/B switches of kernel geometry ("Tried and measured"). */
