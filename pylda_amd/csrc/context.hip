@@ -241,6 +241,9 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     } else if (!strcmp(name, "quad")) {
         ctx->quad = value != 0;
         ctx->plan_epoch += 1;
+    } else if (!strcmp(name, "quad_stream")) {
+        ctx->quad_stream = (int)value;
+        ctx->plan_epoch += 1;
     } else if (!strcmp(name, "quilt12")) {
         ctx->quilt12 = value != 0;
         ctx->plan_epoch += 1;

@@ -372,6 +372,33 @@ __device__ __forceinline__ void lds_row_wait(LdsRow& r)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
 }
 
+// The same row shape fetched from the TABLE (an L2 hit after the document's first iteration): the four
+// global_load_dwordx4 go out now, table_row_wait hands the values over.  The address is a uniform base (scalar
+// registers) plus a 32-bit byte offset per lane - one VGPR per row instead of a pointer pair, in kernels at the
+// register limit; the host only selects these kernels while the table is below 4 GiB.  The wait is vmcnt(0): the
+// loops that use it keep one such row in flight per wavefront, and any older load of the thread has landed by then.
+template <int PIECE>
+__device__ __forceinline__ void table_row_request(LdsRow& r, const void* base, unsigned byte_offset)
+{
+    static_assert(PIECE == 256 || PIECE == 512, "16 or 32 topic lanes");
+    if constexpr (PIECE == 256)
+        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:256\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:512\n\tglobal_load_dwordx4 %3, %4, %5 offset:768"
+                     : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
+                     : "v"(byte_offset), "s"(base)
+                     : "memory");
+    else
+        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:512\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:1024\n\tglobal_load_dwordx4 %3, %4, %5 offset:1536"
+                     : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
+                     : "v"(byte_offset), "s"(base)
+                     : "memory");
+}
+__device__ __forceinline__ void table_row_wait(LdsRow& r)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]) : : "memory");
+}
+
 // sum over aligned groups of LPW (1, 2, 4 or 8) neighbouring lanes; every lane of a group gets it
 template <int LPW>
 __device__ __forceinline__ double lane_group_sum(double s)

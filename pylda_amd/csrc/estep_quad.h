@@ -79,7 +79,28 @@ struct QuadLds {
     static_assert(total <= 160 * 1024, "fits the LDS");
 };
 
-template <int TL, int RWL, int TWL>
+// Which streamed slot a pass handles at its stop P (0: start ... 3: end), or -1: the SWL slots are spread over the pass.
+constexpr int quad_stream_stop(int swl, int stop)
+{
+    return swl == 4 ? stop : swl == 3 ? (stop == 0 ? 0 : stop == 2 ? 1 : stop == 3 ? 2 : -1)
+         : swl == 2 ? (stop == 0 ? 0 : stop == 3 ? 1 : -1) : swl == 1 ? (stop == 0 ? 0 : -1) : -1;
+}
+
+// SWL > 0: word slots beyond the register and LDS capacity - documents of 225-256 terms at stride 256, the 3 % of cfg 4
+// that the two-pass tiered kernel (estep_qwide.h, retired) ran at 950 ns per document.  A streamed slot is a row of
+// the table (an L2 hit: the same CU read it an iteration earlier) read through ONE more 16-VGPR buffer per wavefront
+// and handled exactly like an LDS slot (partial normaliser into the second transpose, r from the row broadcast) - and,
+// like the LDS slots, walked forwards by the normaliser pass and backwards by the topic-sum pass, so the row one pass
+// ends on is the row the next pass starts with: 2 (SWL - 1) table rows per iteration.  The register slots go down to
+// eight to make room (with nine the tile itself spills).  The streamed slots deal their words to the word groups in
+// REVERSE order: a document that fills its last slot only half (three quarters of the class) leaves the empty half to
+// the topic wavefronts - the critical path - which skip the slot, requests included.  Measured, cfg 4 documents of
+// 225-240 terms alone on the chip: 667 ns per document against 944.  What is left is exposed latency: the FMA work
+// of a whole pass is ~0.3 us, less than an L2 round trip, and the one long window of an iteration - the gamma phase -
+// can hide rows only if they stay in registers across it (tried: two or three rows in flight across the gamma phase,
+// consumed at the top of the next iteration in the fused form of estep_qfuse.h; the kernel then spills 150-280 bytes
+// per lane and every reload's vmcnt(0) waits for the rows in flight: 1300 ns per document).
+template <int TL, int RWL, int TWL, int SWL = 0>
 __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepParams p)
 {
     using L = QuadLds<TL, RWL, TWL>;
@@ -87,7 +108,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     constexpr int NT = kWave * W;
     constexpr int KT = 8 * TL;              // padded topic count (== ldk)
     constexpr int KRL = 8;                  // values of a row per lane
-    constexpr int WPG = RWL + TWL;          // word slots per group
+    constexpr int WPG = RWL + TWL + SWL;    // word slots per group
     constexpr int C0 = WPG < 8 ? WPG : 8;   // slots finished in the first transpose
     constexpr int C1 = WPG - C0;            // ... in the second
     constexpr int R1 = RWL > 8 ? RWL - 8 : 0;   // register slots of the second chunk
@@ -97,7 +118,9 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     constexpr int NPIECE = L::kPartials / 2 / FL;   // 16-byte pieces of the transpose each of them reads (4; kPre: 2)
     constexpr int QV = KRL / G;             // topic values per lane after the in-wavefront reduction (2 or 4)
     static_assert(TL == 16 || TL == 32, "ldk 128 or 256");
-    static_assert(RWL >= 2 && RWL <= 10 && TWL >= 0 && TWL <= 4 && WPG <= 16, "word slots per group");
+    constexpr int WPR = RWL + TWL;          // ... of them on chip
+    static_assert(RWL >= 2 && RWL <= 10 && TWL >= 0 && TWL <= 4 && SWL >= 0 && SWL <= 4 && WPG <= 16, "word slots per group");
+    static_assert(SWL == 0 || TWL > 0, "streamed slots come behind the LDS slots of the second chunk");
     static_assert(TWL == 0 || RWL >= 8, "LDS slots belong to the second chunk");
     static_assert(C0 == 8 || TWL == 0, "LDS slots need the eight-slot first chunk");
     static_assert(KT <= NT, "one thread per topic in the gamma phase");
@@ -139,11 +162,14 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     // ---- small loads first: they must not queue behind the tile gather (vmcnt retires in order) ----
     int wid[WPG];
 #pragma unroll
-    for (int s = 0; s < WPG; ++s) wid[s] = s * 16 + gg < N ? p.term_id[lo + s * 16 + gg] : -1;
+    for (int s = 0; s < WPG; ++s) {
+        const int n = s * 16 + (s < WPR ? gg : 15 - gg);      // (streamed slots: groups in reverse order, see above)
+        wid[s] = n < N ? p.term_id[lo + n] : -1;
+    }
     // the words whose normalisers this lane finishes (one of FL lanes): slots cl/2 and 8 + cl/2 of its group
     const int slot0 = cl >> 1, slot1 = 8 + (cl >> 1);
     const int part = (cl & 1) + 2 * half;
-    const int word0 = slot0 * 16 + gg, word1 = slot1 * 16 + gg;
+    const int word0 = slot0 * 16 + gg, word1 = slot1 * 16 + (slot1 < WPR ? gg : 15 - gg);
     const bool live0 = slot0 < C0 && word0 < N;
     const bool live1 = C1 > 0 && slot1 < WPG && word1 < N;
     // lanes whose slot exists in this launch class (the transpose rows of the others are never written)
@@ -157,9 +183,9 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     // a whole pass before it is used); the empty asm keeps the compiler from hoisting the load into a VGPR
     auto count_of = [&](int which) -> double {
         if constexpr (GCNT) {
-            int64_t at = lo + (which ? (live1 ? word1 : 0) : (live0 ? word0 : 0));
+            unsigned at = which ? (live1 ? word1 : 0) : (live0 ? word0 : 0);   // (uniform base + 32-bit index: one VGPR)
             asm volatile("" : "+v"(at));
-            const int ct = p.term_ct[at];
+            const int ct = (p.term_ct + lo)[at];
             return (which ? live1 : live0) ? (double)ct : 0.0;
         } else {
             return cntv[which * NT + tid];
@@ -204,6 +230,17 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         }
 #pragma unroll
         for (int jj = 0; jj < KRL / 2; ++jj) myrows[t * (KT / 2) + TL * jj] = v2[jj];
+    }
+
+    // streamed slots: byte offset of this lane's piece of the row (the table is below 4 GiB: plan.hip); a slot beyond
+    // the document reads row 0 and its partial normaliser is replaced; swave: any live word in this WAVEFRONT (uniform)
+    unsigned srow[SWL > 0 ? SWL : 1];
+    bool slive[SWL > 0 ? SWL : 1], swave[SWL > 0 ? SWL : 1];
+#pragma unroll
+    for (int s = 0; s < SWL; ++s) {
+        slive[s] = wid[WPR + s] >= 0;
+        swave[s] = (WPR + s) * 16 + 15 - (wave * G + G - 1) < N;
+        srow[s] = ((unsigned)(slive[s] ? wid[WPR + s] : 0) * (unsigned)ldk2 + (unsigned)c) * 16u;
     }
 
     // ---- total token count (:162) and the invariant sum_k gamma_k ----
@@ -266,6 +303,9 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     LdsRow rowbuf;
     auto request_row = [&](int t) { lds_row_request<TL * 16>(rowbuf, myrows + t * (KT / 2)); };
     if constexpr (TWL > 0) request_row(0);
+    LdsRow sbuf;
+    auto request_srow = [&](int s) { table_row_request<TL * 16>(sbuf, p.expElog, srow[s]); };
+    if constexpr (SWL > 0) request_srow(0);                               // (slot 0 is never empty: N > 16 * WPR)
     QUAD_STAMP(8);                                                        // prologue: gather, first t
     for (;;) {                                                            // :174
         const int buf = it & 1;
@@ -273,6 +313,23 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         // A. partial normalisers over this lane's topics -> LDS transpose -> sum over the TL topic lanes
         double a[8];
         double pr[TWL > 0 ? TWL : 1];
+        double ps[SWL > 0 ? SWL : 1];
+        auto stream_partial = [&](auto stop) {               // streamed slot s: partial normaliser, next row requested
+            constexpr int s = quad_stream_stop(SWL, decltype(stop)::value);
+            if constexpr (s >= 0) {
+                ps[s] = 1.0;                                 // (an empty slot: any positive normaliser, its count is 0)
+                if (swave[s]) {
+                    table_row_wait(sbuf);
+                    double row[8];
+                    sbuf.unpack(row);
+                    const double d = TL == 16 ? dot8_two_chains(row, tq) : dot8(row, tq);
+                    if (slive[s]) ps[s] = d;
+                    if constexpr (s + 1 < SWL) {
+                        if (swave[s + 1]) request_srow(s + 1);
+                    }
+                }
+            }
+        };
         auto row_partial = [&](auto idx) {                   // LDS slot t: partial normaliser, next row requested
             constexpr int t = decltype(idx)::value;
             if constexpr (t < TWL) {
@@ -283,17 +340,20 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
                 if constexpr (t + 1 < TWL) request_row(t + 1);
             }
         };
+        stream_partial(StaticIndex<0>());
         if constexpr (C0 == 8) {
             col_mul8(a, B[0][0], B[1][0], B[2][0], B[3][0], B[4][0], B[5][0], B[6][0], B[7][0], tq[0]);
             col_fmac8(a, B[0][1], B[1][1], B[2][1], B[3][1], B[4][1], B[5][1], B[6][1], B[7][1], tq[1]);
             col_fmac8(a, B[0][2], B[1][2], B[2][2], B[3][2], B[4][2], B[5][2], B[6][2], B[7][2], tq[2]);
             col_fmac8(a, B[0][3], B[1][3], B[2][3], B[3][3], B[4][3], B[5][3], B[6][3], B[7][3], tq[3]);
             row_partial(StaticIndex<0>());
+            stream_partial(StaticIndex<1>());
             col_fmac8(a, B[0][4], B[1][4], B[2][4], B[3][4], B[4][4], B[5][4], B[6][4], B[7][4], tq[4]);
             col_fmac8(a, B[0][5], B[1][5], B[2][5], B[3][5], B[4][5], B[5][5], B[6][5], B[7][5], tq[5]);
             col_fmac8(a, B[0][6], B[1][6], B[2][6], B[3][6], B[4][6], B[5][6], B[6][6], B[7][6], tq[6]);
             col_fmac8(a, B[0][7], B[1][7], B[2][7], B[3][7], B[4][7], B[5][7], B[6][7], B[7][7], tq[7]);
             row_partial(StaticIndex<1>());
+            stream_partial(StaticIndex<2>());
         } else {
 #pragma unroll
             for (int i = 0; i < C0; ++i) a[i] = dot8(B[i], tq);
@@ -308,6 +368,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         QUAD_STAMP(0);                                                    // t wait + pass A over slots 0-7 (+ rows 0, 1) + writes
         if (moved <= thresh || left <= 0) {                               // :189 (mean <= tol), :174
             if constexpr (TWL > 2) lds_row_wait(rowbuf);                  // no read may land after the loop (row 2 is in flight)
+            if constexpr (SWL > 1) table_row_wait(sbuf);
             break;
         }
         wave_lds_exchange();
@@ -322,6 +383,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             for (int i = 0; i < R1; ++i) a1[i] = TL == 16 ? dot8_two_chains(B[8 + i], tq) : dot8(B[8 + i], tq);
             row_partial(StaticIndex<2>());
             row_partial(StaticIndex<3>());                                // (the last row stays in the buffer: pass B starts with it)
+            stream_partial(StaticIndex<3>());                             // (the last streamed row likewise)
             double s0 = finish_sum(h0);
             asm volatile("" : "+v"(s0));                                  // h0 is dead from here on
             QUAD_STAMP(1);                                                // slots 8.., rows 2, 3, first transpose landed and summed
@@ -332,6 +394,8 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             for (int i = 0; i < R1; ++i) myred[i * RS + cw] = PRE ? lane_group_sum<2>(a1[i]) : a1[i];
 #pragma unroll
             for (int t = 0; t < TWL; ++t) myred[(R1 + t) * RS + cw] = PRE ? lane_group_sum<2>(pr[t]) : pr[t];
+#pragma unroll
+            for (int s = 0; s < SWL; ++s) myred[(R1 + TWL + s) * RS + cw] = PRE ? lane_group_sum<2>(ps[s]) : ps[s];
             wave_lds_exchange();
             double2 h1[NPIECE];
 #pragma unroll
@@ -367,6 +431,18 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
                 if constexpr (t > 0) request_row(t - 1);
             }
         };
+        auto stream_topic_sums = [&](auto stop) {            // the streamed slots backwards
+            constexpr int u = quad_stream_stop(SWL, decltype(stop)::value), s = SWL - 1 - u;
+            if constexpr (u >= 0) {
+                if (swave[s]) {                              // (the first live one is still in the buffer)
+                    table_row_wait(sbuf);
+                    double row[8];
+                    sbuf.unpack(row);
+                    row_bcast_fmac<2 * (R1 + TWL + s)>(q, r1, row);
+                    if constexpr (s > 0) request_srow(s - 1);
+                }
+            }
+        };
         {
             const double rb = row_bcast<0>(r0);            // r of slot i sits in lane 2*i of every 16-lane row of the group
 #pragma unroll
@@ -382,18 +458,22 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             r1 = cnt1h * rcp_newton(s1);
             dpp_source_ready(r1);
         }
+        stream_topic_sums(StaticIndex<0>());
         row_topic_sums(StaticIndex<0>());
+        stream_topic_sums(StaticIndex<1>());
         static_for<(C0 > 4 ? C0 - 4 : 0)>([&](auto idx) {
             constexpr int i = decltype(idx)::value + 4;
             row_bcast_fmac<2 * i>(q, r0, B[i]);
         });
         row_topic_sums(StaticIndex<1>());
+        stream_topic_sums(StaticIndex<2>());
         static_for<R1>([&](auto idx) {
             constexpr int i = decltype(idx)::value;
             row_bcast_fmac<2 * i>(q, r1, B[8 + i]);
         });
         row_topic_sums(StaticIndex<2>());
         row_topic_sums(StaticIndex<3>());
+        stream_topic_sums(StaticIndex<3>());
         // over the word groups of the wavefront; the per-wavefront partials go to the (now idle) transpose area
         wave_lds_exchange();
         double* mysp = red + (size_t)wave * (L::red_wave / 8);
@@ -508,7 +588,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         const double2* gtable = reinterpret_cast<const double2*>(p.expElog_elog);
 #pragma unroll
         for (int s = 0; s < WPG; ++s) {
-            const int n = s * 16 + gg;
+            const int n = s * 16 + (s < WPR ? gg : 15 - gg);
             if (n < N) {
                 const double2* row = gtable + (size_t)p.term_id[lo + n] * ldk2 + c;
                 double gsum2 = 0.0;

@@ -38,8 +38,8 @@ QuiltGeom quilt_geom_for(const pylda_ctx* ctx, int n)
 }
 // Quad kernel (register + LDS tile on 16 word groups; estep_quad.h): K <= 128 (table stride 128): 4
 // wavefronts per document, two documents per CU; 128 < K <= 256 (stride 256): 8 wavefronts, one per CU.
-// Register slots and LDS slots per word group, N <= 16 * (RWL + TWL); code TL * 10000 + RWL * 100 + TWL,
-// or 0.  TWL <= 3: two workgroups inside a CU's 160 KiB of LDS at stride 128, one at stride 256.
+// Register, LDS and streamed slots per word group, N <= 16 * (RWL + TWL + SWL) <= 256; code SWL * 1000000 +
+// TL * 10000 + RWL * 100 + TWL, or 0.  TWL <= 3: two workgroups inside a CU's 160 KiB of LDS at stride 128, one at stride 256.
 int quad_geom_for(const pylda_ctx* ctx, int n)
 {
     if ((ctx->ldk != 128 && ctx->ldk != 256) || !ctx->quad || ctx->lds_limit < 160 * 1024) return 0;
@@ -50,6 +50,11 @@ int quad_geom_for(const pylda_ctx* ctx, int n)
     if (n <= 192) return tl + 1002;
     if (n <= 208) return tl + 1003;
     if (n <= 224) return tl + 1004;
+    // + SWL streamed slots (estep_quad.h), addressed by 32-bit byte offsets into the table
+    if (!ctx->quad_stream || (uint64_t)ctx->V * (uint64_t)ctx->ldk * 8 >= (1ull << 32)) return 0;
+    if (ctx->quad_stream == 2) return n <= 240 ? 2000000 + tl + 904 : n <= 256 ? 3000000 + tl + 904 : 0;
+    if (n <= 240) return 3000000 + tl + 804;
+    if (n <= 256) return 4000000 + tl + 804;
     return 0;
 }
 

@@ -265,6 +265,74 @@ def test_wide_table_kernels_agree(capi, K, V, mean_len):
         assert np.array_equal(out["doc_ll"], again["doc_ll"])
 
 
+def corpus_of_lengths(rng, V, lengths, zipf=0.8):
+    """Documents with exactly the given numbers of distinct terms."""
+    p = 1.0 / np.arange(1, V + 1) ** zipf
+    p /= p.sum()
+    ptr, ids, cts = [0], [], []
+    for n in lengths:
+        u = np.sort(rng.choice(V, size=n, replace=False, p=p))
+        ids.append(u)
+        cts.append(rng.integers(1, 5, size=n))
+        ptr.append(ptr[-1] + n)
+    return np.array(ptr, np.int64), np.concatenate(ids).astype(np.int32), np.concatenate(cts).astype(np.int32)
+
+
+@pytest.mark.parametrize("K", [256, 128, 200, 100])
+def test_quad_kernel_with_streamed_slots(capi, K):
+    """Documents of 225-256 distinct terms at table strides 128 / 256: the quad kernel with three / four word slots
+    streamed from the table (estep_quad.h, SWL), every boundary length, against the C oracle - equal iteration
+    counts, training and held-out, bitwise repeatable - and against the plan without the streamed classes."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(K + 5)
+    V = 3000
+    lengths = [224, 225, 226, 231, 232, 233, 239, 240, 241, 242, 247, 248, 249, 254, 255, 256, 257, 230, 236, 250]
+    ptr, ids, cts = corpus_of_lengths(rng, V, lengths)
+    eta = rng.gamma(100.0, 0.01, (K, V))
+    eta[:, rng.choice(V, V // 4, replace=False)] = 1.0 / V
+    alpha = rng.uniform(0.05, 1.5, K)
+    ctx = capi.Context(K, V)
+    corpus = ctx.corpus(ptr, ids, cts)
+    plan = {(c["kernel"], c["geometry"]): c["documents"] for c in corpus.plan()}
+    tl = 16 if K <= 128 else 32
+    assert plan[("quad", 3000000 + tl * 10000 + 804)] == 9 and plan[("quad", 4000000 + tl * 10000 + 804)] == 9, plan
+    corpus.close()
+    ctx.close()
+    ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
+    out = run(capi, alpha, eta, ptr, ids, cts)
+    check_against(out, ref["gamma"], ref["doc_ll"], ref["iters"])
+    assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+    old = run(capi, alpha, eta, ptr, ids, cts, options=[("quad_stream", 0)])
+    assert np.array_equal(out["iters"], old["iters"])
+    assert rel_err(out["gamma"], old["gamma"]) < 1e-9
+    held_ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, heldout=True)
+    held = run(capi, alpha, eta, ptr, ids, cts, heldout=True)
+    check_against(held, held_ref["gamma"], held_ref["doc_words_ll"], held_ref["iters"], ll_key="doc_words_ll")
+    again = run(capi, alpha, eta, ptr, ids, cts)
+    assert np.array_equal(out["gamma"], again["gamma"]) and np.array_equal(out["sstats"], again["sstats"])
+    assert np.array_equal(out["doc_ll"], again["doc_ll"])
+    for mi, tol in [(1, 1e-6), (2, 1e-6), (50, 1e-2)]:
+        ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
+        out = run(capi, alpha, eta, ptr, ids, cts, max_iter=mi, tol=tol)
+        assert np.array_equal(out["iters"], ref["iters"]), (mi, tol)
+        assert rel_err(out["gamma"], ref["gamma"]) < 1e-9
+    # the fast path (doc_values = 0) leaves through another exit of the kernel
+    ctx = capi.Context(K, V)
+    corpus = ctx.corpus(ptr, ids, cts)
+    ctx.set_alpha(alpha)
+    ctx.set_eta(eta)
+    ctx.set_option("doc_values", 1)
+    ctx.estep(corpus)
+    full_ll = ctx.estep_results(corpus)[0]
+    sst_full = ctx.get_sstats()
+    ctx.set_option("doc_values", 0)
+    ctx.estep(corpus)
+    assert abs(ctx.estep_results(corpus)[0] - full_ll) < 1e-11 * abs(full_ll)
+    assert np.array_equal(ctx.get_sstats(), sst_full)
+    corpus.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("K,V,mean_len", [(500, 1500, 230), (512, 1200, 60), (449, 1500, 700), (480, 1000, 100),
                                           (300, 1500, 210), (384, 1200, 90), (257, 1500, 500), (385, 900, 150)])
 def test_fused_streaming_kernel_agrees(capi, K, V, mean_len):
