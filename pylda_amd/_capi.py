@@ -529,7 +529,7 @@ class Corpus(object):
         return int(self._ctx._lib.pylda_gamma_device(self._h) or 0)
 
     VARIANT_NAMES = {0: "generic64", 1: "generic256", 2: "generic512", 3: "generic_global", 4: "slab",
-                     6: "quilt", 7: "qstream", 8: "qhybrid", 9: "qwide", 10: "quad", 11: "qfuse", 12: "generic_huge", 13: "qfusek"}
+                     6: "quilt", 9: "qgroup", 10: "quad", 11: "qfuse", 12: "generic_huge", 13: "qfusek"}
 
     def plan(self):
         """Launch classes of this corpus: list of dicts (kernel, geometry, documents, terms, kernel_ms)."""

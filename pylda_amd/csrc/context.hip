@@ -85,9 +85,11 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     ctx->device = device;
     ctx->K = K;
     ctx->V = V;
-    // table stride: K rounded up to 16 / 32 / a multiple of 64, from 257 to 1024 to a multiple of 128 (the fused
-    // streaming kernels' rows are 64 lanes x 16-byte pieces)
-    ctx->ldk = K <= 16 ? 16 : K <= 32 ? 32 : K <= 256 ? (K + 63) / 64 * 64 : K <= 1024 ? (K + 127) / 128 * 128 : (K + 63) / 64 * 64;
+    // table stride: K rounded up to 16 / 32 / 64 / 128 / 256 (the strides the register kernels are built for: 129-192
+    // topics run the stride-256 kernels), from 257 to 1024 to a multiple of 128 (the fused streaming kernels' rows are
+    // 64 lanes x 16-byte pieces), beyond to a multiple of 64
+    ctx->ldk = K <= 16 ? 16 : K <= 32 ? 32 : K <= 64 ? 64 : K <= 128 ? 128 : K <= 256 ? 256
+             : K <= 1024 ? (K + 127) / 128 * 128 : (K + 63) / 64 * 64;
     auto bail = [&](int code) {
         g_create_error = ctx->err;
         pylda_destroy(ctx);
@@ -208,7 +210,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return PYLDA_ERR_INVALID;
     if (!strcmp(name, "force_logspace")) ctx->force_logspace = value != 0;
     else if (!strcmp(name, "force_variant")) {
-        if (value < -1 || value > kVariantLast || value == kRetired5)
+        if (value < -1 || value > kVariantLast || value == kRetired5 || value == kRetired7 || value == kRetired8)
             return fail(ctx, PYLDA_ERR_INVALID, "force_variant %lld is not a kernel variant", (long long)value);
         ctx->force_variant = (int)value;
         ctx->plan_epoch += 1;
@@ -242,7 +244,7 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         ctx->quad = value != 0;
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "quad_stream")) {
-        ctx->quad_stream = (int)value;
+        ctx->quad_stream = value != 0;
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "quilt12")) {
         ctx->quilt12 = value != 0;

@@ -303,9 +303,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             switch (L.variant) {
             case kSlab: rc = launch_slab_any(ctx, p, L); break;
             case kQuilt: rc = launch_quilt_any(ctx, p, L); break;
-            case kQstream: rc = launch_qstream_any(ctx, p, L); break;
-            case kQhybrid: rc = launch_qhybrid_any(ctx, p, L); break;
-            case kQwide: rc = launch_qwide_any(ctx, p, L); break;
+            case kQgroup: rc = launch_qgroup(ctx, p, L); break;
             case kQuad: rc = launch_quad_any(ctx, p, L); break;
             case kQfuse: rc = launch_qfuse(ctx, p, L); break;
             case kQfusek: rc = launch_qfusek(ctx, p, L); break;
@@ -339,7 +337,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     // (one workgroup per CU, all resident), so there the pass stays in front of it.
     bool leaves_terms = false;          // (slab and generic kernels always finish their documents themselves)
     for (const Launch& L : c->plan)
-        leaves_terms = leaves_terms || L.variant == kQuad || L.variant == kQuilt || L.variant == kQwide || L.variant == kQfuse || L.variant == kQfusek;
+        leaves_terms = leaves_terms || L.variant == kQuad || L.variant == kQuilt || L.variant == kQgroup || L.variant == kQfuse || L.variant == kQfusek;
     const bool terms_pass = !heldout && !p.want_doc_ll && c->D > 0 && leaves_terms && !ctx->force_logspace;
     const bool terms_beside_gather = terms_pass && c->have_postings && !c->sweep && ctx->terms_overlap;
     if (terms_pass) {

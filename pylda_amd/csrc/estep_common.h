@@ -380,8 +380,14 @@ __device__ __forceinline__ void lds_row_wait(LdsRow& r)
 template <int PIECE>
 __device__ __forceinline__ void table_row_request(LdsRow& r, const void* base, unsigned byte_offset)
 {
-    static_assert(PIECE == 256 || PIECE == 512, "16 or 32 topic lanes");
-    if constexpr (PIECE == 256)
+    static_assert(PIECE == 128 || PIECE == 256 || PIECE == 512, "8, 16 or 32 topic lanes");
+    if constexpr (PIECE == 128)
+        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:128\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:256\n\tglobal_load_dwordx4 %3, %4, %5 offset:384"
+                     : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
+                     : "v"(byte_offset), "s"(base)
+                     : "memory");
+    else if constexpr (PIECE == 256)
         asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:256\n\t"
                      "global_load_dwordx4 %2, %4, %5 offset:512\n\tglobal_load_dwordx4 %3, %4, %5 offset:768"
                      : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])

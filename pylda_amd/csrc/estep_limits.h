@@ -49,12 +49,8 @@ __host__ __device__ inline size_t logspace_lds_bytes(int K)
 #endif
 constexpr int kQfMaxSlots = PYLDA_QF_SLOTS;   // word slots per wavefront: documents up to 1024 distinct terms
 
-// ---- estep_qhybrid.h ----
-constexpr int kQhMaxTail = 96;              // tier L + S words per wavefront (8 waves: 768 words)
-
-// ---- estep_qwide.h ----
-constexpr int kQwMaxTail = 64;              // tier L + S words per wavefront (8 waves: 512 words)
-constexpr int kQwRegWords = 128;            // tier R words per document (8 waves x 2 groups x 8)
+// ---- estep_qgroup.h ----
+constexpr int kQgMaxWords = 1024;           // distinct terms per document
 
 // ---- mstep_kernels.h: parameters of alpha_newton_kernel (variational_bayes.py:277-324) ----
 struct NewtonParams {

@@ -5,7 +5,7 @@
 //   plan.hip           launch classes: kernel variant and geometry per distinct-term count (host code only)
 //   launch_small.hip   document kernels, generic / slab / quilt families
 //   launch_quad.hip    ... the register + LDS tile kernel (strides 128 / 256)
-//   launch_stream.hip  ... the streaming families (qfuse, qfusek, qstream, qhybrid, qwide)
+//   launch_stream.hip  ... the fused streaming families (qfuse, qfusek, qgroup)
 //   sstats_gather.hip  postings, segments and the statistics pass (dispatch-paced gather, persistent sweep)
 //   estep_api.hip      corpus upload, pylda_estep and its read-backs
 //   mstep_api.hip      device M-step, pack, alpha update, the outer iteration's one read-back
@@ -44,9 +44,9 @@ enum Variant : int {
     kSlab = 4,          // tile in registers, word-major lanes (estep_slab.h)
     kRetired5 = 5,      // (the topic-major column kernel of round 1: measured 2x slower than the quilt layout, removed)
     kQuilt = 6,         // tile in registers, 4 x 16 word-group x topic lanes (estep_quilt.h)
-    kQstream = 7,       // tile streamed from L2 twice per iteration, quilt lanes (estep_qstream.h)
-    kQhybrid = 8,       // tile split over registers / LDS / streamed remainder (estep_qhybrid.h)
-    kQwide = 9,         // the same three tiers on a 2 x 32 lane grid with prefetched tail rows (estep_qwide.h)
+    kRetired7 = 7,      // (rounds 1-2: two-pass streaming, hybrid and wide tiered kernels - their streamed tier was read
+    kRetired8 = 8,      //  twice per iteration; replaced by the quad kernel's streamed slots and estep_qgroup.h)
+    kQgroup = 9,        // table stride 128 / 256, more than 256 terms: rows streamed once per iteration, fused per word group (estep_qgroup.h)
     kQuad = 10,         // 16 word groups / document, tile in registers + LDS rows (estep_quad.h)
     kQfuse = 11,        // table stride 512: rows streamed ONCE per iteration, normaliser and topic sums fused (estep_qfuse.h)
     kGenericHuge = 12,  // a document too long even for its per-term scalars in LDS: those in global memory too (estep_generic.h MODE 2)
@@ -266,9 +266,7 @@ int launch_quilt_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_qfuse(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_qfusek(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
-int launch_qstream_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
-int launch_qhybrid_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
-int launch_qwide_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
+int launch_qgroup(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 
 // ---- sstats_gather.hip ----
 int build_postings(pylda_corpus* c);

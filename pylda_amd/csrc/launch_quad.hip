@@ -33,14 +33,9 @@ int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     case 321002: return launch_quad<32, 10, 2>(ctx, p, L);
     case 321003: return launch_quad<32, 10, 3>(ctx, p, L);
     case 321004: return launch_quad<32, 10, 4>(ctx, p, L);
-    // ... + streamed slots (code + 1000000 * SWL): 225-240 and 241-256 terms (eight register slots: with nine the
-    // tile itself spills)
+    // ... + streamed slots (code + 1000000 * SWL): 225-240 and 241-256 terms
     case 2160904: return launch_quad<16, 9, 4, 2>(ctx, p, L);
     case 3160904: return launch_quad<16, 9, 4, 3>(ctx, p, L);
-    case 2320904: return launch_quad<32, 9, 4, 2>(ctx, p, L);
-    case 3320904: return launch_quad<32, 9, 4, 3>(ctx, p, L);
-    case 3160804: return launch_quad<16, 8, 4, 3>(ctx, p, L);
-    case 4160804: return launch_quad<16, 8, 4, 4>(ctx, p, L);
     case 3320804: return launch_quad<32, 8, 4, 3>(ctx, p, L);
     case 4320804: return launch_quad<32, 8, 4, 4>(ctx, p, L);
     }

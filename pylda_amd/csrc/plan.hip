@@ -52,32 +52,20 @@ int quad_geom_for(const pylda_ctx* ctx, int n)
     if (n <= 224) return tl + 1004;
     // + SWL streamed slots (estep_quad.h), addressed by 32-bit byte offsets into the table
     if (!ctx->quad_stream || (uint64_t)ctx->V * (uint64_t)ctx->ldk * 8 >= (1ull << 32)) return 0;
-    if (ctx->quad_stream == 2) return n <= 240 ? 2000000 + tl + 904 : n <= 256 ? 3000000 + tl + 904 : 0;
-    if (n <= 240) return 3000000 + tl + 804;
-    if (n <= 256) return 4000000 + tl + 804;
-    return 0;
+    // (stride 128: nine register slots + 2 / 3 streamed - 319 ns per document on cfg 3's 225-256-term class against 326 for the
+    //  quilt kernel and 332 with eight; stride 256: eight + 3 / 4 - 591 against 595 with nine, and no scratch)
+    if (ctx->ldk == 128) return n <= 240 ? 2000000 + tl + 904 : n <= 256 ? 3000000 + tl + 904 : 0;
+    return n <= 240 ? 3000000 + tl + 804 : n <= 256 ? 4000000 + tl + 804 : 0;
 }
 
 int quilt_rwl_for(const pylda_ctx* ctx, int n) { const QuiltGeom q = quilt_geom_for(ctx, n); return q.W * 100 + q.RWL; }
 
-// Hybrid kernel: 128 < K <= 256 (ldk 192 / 256), or long documents at ldk 64 / 128.
-bool qhybrid_ok(const pylda_ctx* ctx, int n)
+// Group-fused streaming kernel (estep_qgroup.h): table stride 64 / 128 / 256 (32-bit byte offsets into the table),
+// documents up to 1024 distinct terms.
+bool qgroup_ok(const pylda_ctx* ctx, int n)
 {
-    return ctx->ldk % 64 == 0 && ctx->ldk <= 256 && n <= 128 + 8 * (kQhMaxTail - 4) && ctx->lds_limit >= 160 * 1024;
+    return (ctx->ldk == 64 || ctx->ldk == 128 || ctx->ldk == 256) && n <= kQgMaxWords && (uint64_t)ctx->V * (uint64_t)ctx->ldk * 8 < (1ull << 32);
 }
-
-// Wide tiered kernel: ldk 128 / 192 / 256, documents up to 624 distinct terms.
-bool qwide_ok(const pylda_ctx* ctx, int n)
-{
-    return (ctx->ldk == 128 || ctx->ldk == 192 || ctx->ldk == 256) && n <= kQwRegWords + 8 * (kQwMaxTail - 2) &&
-           ctx->lds_limit >= 160 * 1024;
-}
-
-// 1: one round of tail steps per wavefront (at most 8 steps = 16 words: N <= 256), 2: several.
-int qwide_rounds_for(int n) { return n <= kQwRegWords + 8 * 16 ? 1 : 2; }
-
-// Streaming quilt kernel: any ldk that is a multiple of 64 up to 512, documents up to 1000 terms.
-bool qstream_ok(const pylda_ctx* ctx, int n) { return ctx->ldk % 64 == 0 && ctx->ldk <= 512 && n <= 1000; }
 
 // Decide the kernel variant for a document with n distinct terms.
 int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
@@ -110,19 +98,14 @@ int choose_variant(const pylda_ctx* ctx, int n, size_t* lds_bytes)
         *lds_bytes = 0;
         return kSlab;
     }
-    if ((ctx->force_variant < 0 || ctx->force_variant == kQwide) && qwide_ok(ctx, n)) {
+    if ((ctx->force_variant < 0 || ctx->force_variant == kQgroup) && qgroup_ok(ctx, n)) {
         *lds_bytes = 0;
-        return kQwide;
-    }
-    if ((ctx->force_variant < 0 || ctx->force_variant == kQhybrid) && qhybrid_ok(ctx, n)) {
-        *lds_bytes = 0;
-        return kQhybrid;
-    }
-    if ((ctx->force_variant < 0 || ctx->force_variant == kQstream) && qstream_ok(ctx, n)) {
-        *lds_bytes = 0;
-        return kQstream;
+        return kQgroup;
     }
 generic:
+    // (a request within 3 KiB of the CU's 160 KiB is refused by hipFuncSetAttribute - found with 540-term documents at
+    //  K = 32, 162 608 bytes; the quad kernel's 160 512 are accepted)
+    constexpr size_t kLdsMargin = 3072;
     const int K = ctx->K, stride = tile_stride_for(K);
     const size_t l64 = generic_lds_layout(K, n, stride, 64, false).total;
     const size_t l256 = generic_lds_layout(K, n, stride, 256, false).total;
@@ -132,11 +115,11 @@ generic:
     else if (ctx->force_variant == kGenericHuge) v = kGenericGlobal;
     else if (l64 <= 20 * 1024) v = kGeneric64;
     else if (l256 <= 64 * 1024) v = kGeneric256;
-    else if (l512 <= ctx->lds_limit) v = kGeneric512;
+    else if (l512 + kLdsMargin <= ctx->lds_limit) v = kGeneric512;
     else v = kGenericGlobal;
     // a forced LDS variant that does not fit degrades to the global-tile kernel
     const size_t need = v == kGeneric64 ? l64 : v == kGeneric256 ? l256 : l512;
-    if (v != kGenericGlobal && need > ctx->lds_limit) v = kGenericGlobal;
+    if (v != kGenericGlobal && need + kLdsMargin > ctx->lds_limit) v = kGenericGlobal;
     // ... and a document whose per-term scalars (28 bytes per distinct term) do not fit either keeps those in
     // global memory as well: any length runs
     if (v == kGenericGlobal && (ctx->force_variant == kGenericHuge || generic_lds_layout(K, n, stride, 256, true).total > ctx->lds_limit))
@@ -171,7 +154,7 @@ void build_plan(pylda_corpus* c)
         Run r{i, j - i, n, 0, 0, 0, 0};
         r.variant = choose_variant(ctx, n, &r.lds);
         r.sub = r.variant == kQuilt ? quilt_rwl_for(ctx, n) : r.variant == kQuad ? quad_geom_for(ctx, n)
-              : r.variant == kQwide ? qwide_rounds_for(n) : r.variant == kSlab ? slab_geom_for(ctx, n).RN : 0;
+              : r.variant == kSlab ? slab_geom_for(ctx, n).RN : 0;
         r.rk = r.variant == kSlab ? slab_geom_for(ctx, n).RK : 0;
         runs.push_back(r);
         i = j;

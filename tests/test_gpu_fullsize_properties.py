@@ -104,10 +104,13 @@ def test_oracle_spot_check_on_full_size_run(cfg3):
     docs = np.sort(rng.choice(c["D"], 24, replace=False))
     order = np.argsort(np.diff(c["ptr"]))
     docs = np.unique(np.concatenate([docs, order[:2], order[-2:]]))      # plus the shortest and longest
-    if c["name"] == "cfg4":             # the longest have > 256 distinct terms: the wide kernel's multi-round class
+    if c["name"] == "cfg4":             # the longest have > 256 distinct terms: the group-fused streaming kernel
         assert np.diff(c["ptr"])[order[-1]] > 256
         kernels = {(p["kernel"], p["geometry"]) for p in c["corpus"].plan()}
-        assert ("qwide", 1) in kernels and ("qwide", 2) in kernels, kernels       # 209..256 and > 256 distinct terms
+        assert ("qgroup", 0) in kernels, kernels                                      # > 256 distinct terms
+        assert ("quad", 3320804) in kernels and ("quad", 4320804) in kernels, kernels # 225..256: streamed word slots
+        long_docs = order[np.diff(c["ptr"])[order] > 224]
+        docs = np.unique(np.concatenate([docs, long_docs[:: max(1, len(long_docs) // 6)]]))
         assert ("quad", 321003) in kernels and ("quad", 321002) in kernels, kernels   # the bulk: all words on chip
     from conftest import csr_slice
     ptr, tid, tct = csr_slice(c["ptr"], c["ids"], c["cts"], docs)
