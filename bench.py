@@ -13,21 +13,24 @@ cached between steps).  Inputs are resident in HBM before the timed region.
 torch.distributed.run; under an existing launcher (RANK/WORLD_SIZE set) it is a rank.
 
 Workloads (BASELINE.json configs):
-  synth100k  cfg 3: synthetic LDA corpus, 100,000 docs PER GPU, V=50k, K=128,
-             mean 200 tokens/doc - weak scaling (default primary line; the
-             single-GPU roofline configuration)
   synth1m    cfg 4: 1,000,000 docs TOTAL, V=100k, K=256, sharded over N GPUs -
-             strong scaling
+             strong scaling (default primary line)
+  synth100k  cfg 3: synthetic LDA corpus, 100,000 docs PER GPU, V=50k, K=128,
+             mean 200 tokens/doc - weak scaling
   ap         cfg 2: associated-press train split (committed parsed fixture),
              K=10, replicated per GPU (latency-bound, 2000 documents)
   nips       cfg 5: parsed/nips.88-05 (committed parsed fixture), K=500,
              train = first 2,235 documents
 
-The default run prints ONE JSON line on rank 0: the primary record (cfg 3) with
-`roofline` and `cpu_baseline`, and as sub-records the other configurations timed
-in the same processes at every N: `synth1m` (cfg 4), `ap_k10` (cfg 2) and
-`nips_k500` (cfg 5: the 50-iteration joint log-likelihood trace asserted against
-the reference's own, held-out per-token log-likelihood after 50 iterations).
+The default run prints ONE JSON line on rank 0: the primary record - cfg 4, the
+1M-document corpus north_star quotes 1/2/4/8-GPU throughput on, sharded over the
+N ranks (strong scaling), the same workload at every N - with `roofline` and
+`cpu_baseline`, and as sub-records the other configurations timed in the same
+processes at every N: `synth100k` (cfg 3, the top-level record of rounds 1-4),
+`ap_k10` (cfg 2) and `nips_k500` (cfg 5: the 50-iteration joint log-likelihood
+trace asserted against the reference's own, held-out per-token log-likelihood
+after 50 iterations).  At N = 1 `shard_proxy` / `nips_k500.shard_proxy` time rank
+0's shard for N = 2 / 4 / 8 on the one GPU (a model of the curve, labelled so).
 
 Protocol: 3 warm-up outer iterations from the seeded start, then
 outer iterations 4-8 are THE timed window, whatever --steps / --warmup say: timed
@@ -71,13 +74,16 @@ def algorithmic_bytes(nnz, D, K):
     return nnz * (8 + 16 * K) + D * (8 * K + 8)
 
 
-def kernel_source_hash():
-    """sha256 over the kernel sources whose HBM traffic profiles/traffic_*.json describes."""
+def kernel_source_hash(csrc=None):
+    """sha256 over the DEVICE sources whose HBM traffic profiles/traffic_*.json describes: the kernel headers of the
+    E-step and of the statistics pass.  Host translation units (*.hip, *.cpp) are not part of it: an edit to the
+    launcher or to a test hook does not change what the kernels move (tests/test_host_logic.py pins that)."""
     import hashlib
     h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "pylda_amd", "csrc")
+    csrc = csrc or os.path.join(ROOT, "pylda_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.startswith("estep_") or f in ("sstats_kernels.h", "sstats_sweep.h", "doc_terms.h"):
+        if f.endswith(".h") and (f.startswith("estep_") or f.startswith("sstats_")
+                                 or f in ("doc_terms.h", "special_device.h", "prepare_kernels.h")):
             h.update(f.encode())
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
@@ -462,7 +468,7 @@ def shard_proxy(job, args, step_ms_full):
     from pylda_amd.variational_bayes import VariationalBayes
     rows = []
     for n in (2, 4, 8):
-        wl = build_workload("synth1m", 0, n, job.device, args.extra_docs)
+        wl = build_workload("synth1m", 0, n, job.device, args.docs)
         ptr, ids, cts, V, K = wl["ptr"], wl["ids"], wl["cts"], wl["V"], wl["K"]
         np.random.seed(0)
         eta0 = np.random.gamma(100., 1. / 100., (K, V))
@@ -495,7 +501,7 @@ def shard_proxy(job, args, step_ms_full):
         direct = 2.0 * nbytes / n / (XGMI_LINK_GBPS * 1e9) * 1e3
         step = float(np.mean(walls))
         predicted = step + ring
-        total_docs = args.extra_docs or 1000000
+        total_docs = args.docs or 1000000
         rows.append({"n_gpus_modelled": n, "docs_rank0": len(ptr) - 1, "nnz_rank0": int(ptr[-1]),
                      "ms_per_step_measured": step, "kernel_ms_documents": doc_ms, "kernel_ms_sstats": ss_ms,
                      "estep_span_ms": float(np.mean(e_span)), "mstep_span_ms": float(np.mean(m_span)),
@@ -532,7 +538,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="synth100k", choices=["synth100k", "synth1m", "ap", "nips"])
+    ap.add_argument("--workload", default="synth1m", choices=["synth100k", "synth1m", "ap", "nips"])
     ap.add_argument("--docs", type=int, default=None, help="override the corpus size (smoke runs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--cpu-workers", type=int, default=32,
@@ -541,10 +547,10 @@ def main():
                          "(the gathered K x V table does not fit its caches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", "--no-ap-extra", dest="no_extras", action="store_true",
-                    help="primary record only (no cfg 2 / cfg 4 / cfg 5 sub-records)")
+                    help="primary record only (no cfg 2 / cfg 3 / cfg 5 sub-records)")
     ap.add_argument("--no-shard-proxy", action="store_true",
                     help="skip the single-GPU proxy of the cfg 4 strong-scaling curve (rank 0's shard for N = 2 / 4 / 8 + modelled exchange)")
-    ap.add_argument("--extra-docs", type=int, default=None, help="corpus size of the cfg 4 sub-record (smoke runs)")
+    ap.add_argument("--extra-docs", type=int, default=None, help="corpus size (per GPU) of the cfg 3 sub-record (smoke runs)")
     ap.add_argument("--variant", type=int, default=-1, help="force a kernel variant (A/B runs)")
     ap.add_argument("--option", action="append", default=[], help="name=value library option (A/B runs)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -570,38 +576,44 @@ def main():
             "roofline_fp64": rec["roofline_fp64"], "doc_iterations_per_s": rec["doc_iterations_per_s"],
             "protocol": rec["protocol"],
             "joint_log_likelihood": rec["joint_log_likelihood"], "startup": rec["startup"],
+            "primary_workload_note": "since round 5 the top-level record is cfg 4 (the 1M-document corpus north_star "
+                                     "quotes 1/2/4/8-GPU throughput on, strong scaling) at EVERY N; rounds 1-4 had cfg 3 "
+                                     "there, which is now the sub-record `synth100k` (same protocol, comparable with "
+                                     "BENCH_r01-r04's top level)",
         }
         if not args.no_cpu_baseline and job.world == 1:
-            out.update(cpu_leg(ctx, vb, wl, args, args.cpu_seconds, 2000, rec["value"], all_cores=args.cpu_workers))
+            out.update(cpu_leg(ctx, vb, wl, args, args.cpu_seconds, 2000 if args.workload != "synth1m" else 600, rec["value"],
+                               all_cores=args.cpu_workers))
         if job.world == 1:
             out["host_array_contract"] = host_contract_leg(vb)
     release(vb)
     del vb, ctx, wl
 
-    extras = not args.no_extras and args.workload == "synth100k"
+    extras = not args.no_extras and args.workload == "synth1m"
+    if extras and job.world == 1 and not args.no_shard_proxy:
+        # ---- single-GPU proxy of the strong-scaling curve: rank 0's shard of cfg 4 for N = 2 / 4 / 8 ----
+        out["shard_proxy"] = shard_proxy(job, args, rec["ms_per_step"])
     if extras:
-        # ---- cfg 4 (1M documents, K=256) alongside, every N: strong scaling + its own roofline ----
+        # ---- cfg 3 (100k documents per GPU, K=128) alongside, every N: weak scaling + its own roofline ----
         try:
-            rec4, vb4, ctx4, wl4 = measure(job, args, "synth1m", PROTOCOL_WINDOW, PROTOCOL_WARMUP, args.extra_docs)
+            rec3, vb3, ctx3, wl3 = measure(job, args, "synth100k", PROTOCOL_WINDOW, PROTOCOL_WARMUP, args.extra_docs)
             if job.rank == 0:
-                sub = {"value": rec4["value"], "unit": "docs/s", "n_gpus": job.world, "steps": PROTOCOL_WINDOW,
-                       "warmup": PROTOCOL_WARMUP, "ms_per_step": rec4["ms_per_step"], "scaling": "strong",
-                       "config": rec4["config"], "roofline": rec4["roofline"], "roofline_fp64": rec4["roofline_fp64"],
-                       "doc_iterations_per_s": rec4["doc_iterations_per_s"], "protocol": rec4["protocol"],
-                       "startup": rec4["startup"]}
+                sub = {"value": rec3["value"], "unit": "docs/s", "n_gpus": job.world, "steps": PROTOCOL_WINDOW,
+                       "warmup": PROTOCOL_WARMUP, "ms_per_step": rec3["ms_per_step"], "scaling": "weak",
+                       "config": rec3["config"], "roofline": rec3["roofline"], "roofline_fp64": rec3["roofline_fp64"],
+                       "doc_iterations_per_s": rec3["doc_iterations_per_s"], "protocol": rec3["protocol"],
+                       "startup": rec3["startup"]}
                 if not args.no_cpu_baseline and job.world == 1:
-                    sub.update(cpu_leg(ctx4, vb4, wl4, args, min(args.cpu_seconds, 10.0), 400, rec4["value"]))
-                out["synth1m"] = sub
-            release(vb4)
-            del vb4, ctx4, wl4
-            if job.world == 1 and not args.no_shard_proxy:
-                out["synth1m"]["shard_proxy"] = shard_proxy(job, args, rec4["ms_per_step"])
+                    sub.update(cpu_leg(ctx3, vb3, wl3, args, min(args.cpu_seconds, 10.0), 1000, rec3["value"]))
+                out["synth100k"] = sub
+            release(vb3)
+            del vb3, ctx3, wl3
         except AssertionError:
             raise
         except Exception as exc:
             if job.group is not None:
                 raise
-            out["synth1m"] = {"error": repr(exc)}
+            out["synth100k"] = {"error": repr(exc)}
     if extras:
         # ---- cfg 2 (associated-press K=10) and cfg 5 (nips.88-05 K=500), every N: documents sharded over the ranks ----
         for key, fn in (("ap_k10", ap_extra), ("nips_k500", nips_extra)):
@@ -745,6 +757,8 @@ def nips_extra(job, args):
         if n_iter in heldout:
             out["reference_heldout_per_token_log_likelihood"] = heldout[n_iter] / tokens
             out["heldout_rel_delta"] = abs(wll - heldout[n_iter]) / abs(heldout[n_iter])
+        if job.world == 1 and not args.no_shard_proxy:
+            out["shard_proxy"] = nips_shard_proxy(job, g, out["ms_per_step"])
         if not args.no_cpu_baseline and job.world == 1:
             rate, n, _ = cpu_baseline(m._alpha_alpha.copy(), m._eta.copy(), ptr, ids, cts, min(args.cpu_seconds, 10.0), 200)
             out["cpu_baseline"] = {"value": rate, "unit": "docs/s", "cores": 1, "kind": "port",
@@ -753,6 +767,53 @@ def nips_extra(job, args):
     job.barrier()
     release(m)
     return out
+
+
+def nips_shard_proxy(job, g, step_ms_full):
+    """Single-GPU PROXY of cfg 5 on N = 2 / 4 / 8 GPUs (BASELINE.json puts it on 8): rank 0's nnz-balanced shard of the
+    2235 training documents (1118 / 559 / 280) with the full K x V model, timed alone on this GPU, + the modelled ring
+    all-reduce of the K x V statistics.  A document is one workgroup on one CU and its 50 inner iterations are a
+    serial chain, so the step cannot shrink below ceil(documents / CUs) chains: `residency_rounds`."""
+    from pylda_amd.corpus import shard_bounds
+    from pylda_amd.variational_bayes import VariationalBayes
+    K, V = int(g["K"]), len(g["words"])
+    ptr, ids, cts = g["doc_ptr"].astype(np.int64), g["term_id"].astype(np.int32), g["term_ct"].astype(np.int32)
+    rows = []
+    for n in (2, 4, 8):
+        hi = int(shard_bounds(ptr, n)[1])
+        np.random.seed(int(g["seed"]))
+        m = VariationalBayes(device=job.local_rank)
+        m._verbose = False
+        m._initialize_parsed(ptr[:hi + 1], ids[:ptr[hi]], cts[:ptr[hi]], V, K, 1.0 / K, 1.0 / V)
+        ctx = m._context()
+        for _ in range(5):
+            m.learning()
+        ctx.synchronize()
+        ctx.set_profiling(True)
+        ctx.kernel_time()
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.learning()
+        ctx.synchronize()
+        step = (time.perf_counter() - t0) / reps * 1e3
+        doc_ms, ss_ms, calls = ctx.kernel_time()
+        classes = m._train_corpus.plan()
+        ctx.set_profiling(False)
+        calls = max(1, calls)
+        num_cu = job.torch.cuda.get_device_properties(job.device).multi_processor_count
+        ring = 2.0 * (n - 1) / n * V * K * 8 / (XGMI_LINK_GBPS * 1e9) * 1e3
+        rows.append({"n_gpus_modelled": n, "docs_rank0": hi, "nnz_rank0": int(ptr[hi]), "ms_per_step_measured": step,
+                     "kernel_ms_documents": doc_ms / calls, "kernel_ms_sstats": ss_ms / calls,
+                     "launch_classes": [(c["kernel"], c["geometry"], c["documents"]) for c in classes],
+                     "residency_rounds": -(-hi // num_cu), "allreduce_ms_model_ring": ring,
+                     "predicted_ms_per_step": step + ring,
+                     "predicted_speedup_vs_n1": step_ms_full / (step + ring)})
+        release(m)
+    return {"model": True, "ms_per_step_n1": step_ms_full, "per_n": rows,
+            "note": "NOT a multi-GPU measurement: rank 0's shard of the nips.88-05 training split for N = 2 / 4 / 8 timed on "
+                    "ONE GPU (iterations 6-25 from the seeded start of the SHARD's own model) + a modelled, non-overlapped ring "
+                    "all-reduce of the K x V statistics at %.0f GB/s per xGMI link" % XGMI_LINK_GBPS}
 
 
 if __name__ == "__main__":

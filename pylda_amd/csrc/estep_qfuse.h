@@ -41,8 +41,8 @@ struct QfuseLds {
     static constexpr size_t gpv = alf + (size_t)kTopics * 8;                       // [kTopics] gamma before the last update
     static constexpr size_t chg = gpv + (size_t)kTopics * 8;                       // u64[2]
     static constexpr size_t misc = chg + 16;                                       // [8][W]
-    static constexpr size_t ids = misc + (size_t)8 * W * 8;                        // int [W][kQfMaxSlots]
-    static constexpr size_t cnt = ids + (size_t)W * kQfMaxSlots * 4;               // double [W][kQfMaxSlots]
+    static constexpr size_t ids = misc + (size_t)8 * W * 8;                        // u64 [W][kQfMaxSlots] byte offset of the slot's row in the table
+    static constexpr size_t cnt = ids + (size_t)W * kQfMaxSlots * 8;               // double [W][kQfMaxSlots]
     static constexpr size_t rr = cnt + (size_t)W * kQfMaxSlots * 8;                // double [W][kQfMaxSlots]  r of the last iteration
     static constexpr size_t rows = (rr + (size_t)W * kQfMaxSlots * 8 + 255) & ~(size_t)255;   // [W][TWL][kTopics]
     static constexpr size_t total = rows + (size_t)W * TWL * kTopics * 8;
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     constexpr int W = 8, NT = 512, KT = 128 * NP, KRL = 2 * NP;
     static_assert(NP == 3 || NP == 4, "table stride 384 or 512");
     static_assert(RWL % 2 == 0 && TWL % 2 == 0, "words are processed in pairs");
+    static_assert((RWL + TWL) % 4 == 0, "the on-chip words go four to a reduction");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sp = reinterpret_cast<double*>(smem + L::sp);
     double* tt = reinterpret_cast<double*>(smem + L::tt);
@@ -150,19 +151,20 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     constexpr int kOnChip = RWL + TWL;
     const int NS = S > kOnChip ? (S - kOnChip + 3) & ~3 : 0;   // streamed slots, padded to whole trips of four
     const int Spad = kOnChip + NS;
-    int* myids = reinterpret_cast<int*>(smem + L::ids) + wave * kQfMaxSlots;
+    unsigned long long* myoff = reinterpret_cast<unsigned long long*>(smem + L::ids) + wave * kQfMaxSlots;
     double* mycnt = reinterpret_cast<double*>(smem + L::cnt) + wave * kQfMaxSlots;
     double* myrr = reinterpret_cast<double*>(smem + L::rr) + wave * kQfMaxSlots;
     double2* myrows = reinterpret_cast<double2*>(smem + L::rows) + (size_t)wave * TWL * (KT / 2) + c;
-    const double2* table = reinterpret_cast<const double2*>(p.expElog);
-    const int ldk2 = ldk / 2;
+    // this lane's first piece of row 0: a row's address is one 64-bit add of the slot's byte offset (kept in LDS)
+    const char* table = reinterpret_cast<const char*>(reinterpret_cast<const double2*>(p.expElog) + c);
+    const unsigned long long row_bytes = (unsigned long long)ldk * 8;
 
     // ---- word ids / counts of this wavefront's slots, token total (:162) ----
     double local = 0.0;
     for (int s = c; s < Spad; s += kWave) {
         const int n = s * W + wave;
         const bool live = n < N;
-        myids[s] = live ? p.term_id[lo + n] : 0;            // dead slots: a valid row, count 0 => r = 0
+        myoff[s] = (live ? (unsigned long long)p.term_id[lo + n] : 0ull) * row_bytes;   // dead slots: a valid row, count 0 => r = 0
         const double ct = live ? (double)p.term_ct[lo + n] : 0.0;
         mycnt[s] = ct;
         myrr[s] = 0.0;
@@ -177,13 +179,13 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     if (topic_thread) alf[tid] = topic_live ? p.alpha[tid] : 1.0;
     if (c == 0) misc[wave] = local;
     if (tid == 0) chg[0] = chg[1] = 0ull;
-    __syncthreads();                                        // also: myids / mycnt are in place
+    __syncthreads();                                        // also: myoff / mycnt are in place
 
     // ---- on-chip tiers: registers, LDS rows ----
     double B[RWL][KRL];
 #pragma unroll
     for (int i = 0; i < RWL; ++i) {
-        const double2* row = table + (size_t)myids[i] * ldk2 + c;
+        const double2* row = reinterpret_cast<const double2*>(table + myoff[i]);
 #pragma unroll
         for (int jj = 0; jj < NP; ++jj) {
             const double2 v2 = row[64 * jj];
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     }
 #pragma unroll
     for (int t = 0; t < TWL; ++t) {
-        const double2* row = table + (size_t)myids[RWL + t] * ldk2 + c;
+        const double2* row = reinterpret_cast<const double2*>(table + myoff[RWL + t]);
 #pragma unroll
         for (int jj = 0; jj < NP; ++jj) myrows[t * (KT / 2) + 64 * jj] = row[64 * jj];
     }
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
 
     int it = 0;
     int bad = 0;
-    auto row_address = [&](int slot) { return (const void*)(table + (size_t)myids[slot] * ldk2 + c); };
+    auto row_address = [&](int slot) { return (const void*)(table + myoff[slot]); };
     while (it < p.max_iter) {                                             // :174
         const int buf = it & 1;
         double tq[KRL];
@@ -230,10 +232,11 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
         // 32-63), so the five remaining reduction levels, the range check and the reciprocal run once for both.
         auto word_pair = [&](const double (&rowA)[KRL], const double (&rowB)[KRL], int slot) {
             const double nrm = half_wave_sum(swap32_add(lane_dot(rowA, tq), lane_dot(rowB, tq)));
+            // (B, t <= 1: a normaliser cannot overflow; NaN fails the compare; an empty slot reads row 0 of the table with
+            //  count 0: a positive normaliser like any word's, r = 0 without a select)
             const double cnt = mycnt[slot + (c >> 5)];
-            const bool live = cnt > 0.0;
-            if (live && !(nrm > 1e-280 && nrm < 1e300)) bad = 1;
-            const double r = live ? cnt * rcp_newton(nrm) : 0.0;
+            if (!(nrm > 1e-280)) bad = 1;
+            const double r = cnt * rcp_newton(nrm);
             if ((c & 31) == 0) myrr[slot + (c >> 5)] = r;
             const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(r), __double2loint(r), false, false);
             const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(r), __double2hiint(r), false, false);
@@ -243,25 +246,64 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
 #pragma unroll
             for (int j = 0; j < KRL; ++j) q[j] = fma(rB, rowB[j], q[j]);
         };
+        // FOUR on-chip words (slots slot .. slot + 3): two swap levels fold the four per-lane dots into one register -
+        // 16-lane row 0 holds word A's partial sums, row 1 C's, row 2 B's, row 3 D's - so the four remaining reduction
+        // levels, the range check and the reciprocal run once for all four, and three swaps hand every r to every lane:
+        // 21 + 12 + 6 instructions around the 4 x (11 + 8) of the dots and the topic sums, where two pairs take 36 + 24 + 4.
+        // (The streamed words stay in pairs: four rows in use and none in flight would expose every L2 round trip.)
+        auto word_quad = [&](const double (&rowA)[KRL], const double (&rowB)[KRL], const double (&rowC)[KRL],
+                             const double (&rowD)[KRL], int slot) {
+            double nrm = swap16_add(swap32_add(lane_dot(rowA, tq), lane_dot(rowB, tq)),
+                                    swap32_add(lane_dot(rowC, tq), lane_dot(rowD, tq)));
+            nrm = lane_group_sum<8>(nrm);
+            nrm += dpp_f64<0x140>(nrm);                       // row_mirror: the other half of the 16-lane row
+            const int mine = ((c >> 4) & 1) * 2 + (c >> 5);    // the word whose normaliser this lane's row holds: A, C, B, D
+            const double cnt = mycnt[slot + mine];
+            if (!(nrm > 1e-280)) bad = 1;
+            const double r = cnt * rcp_newton(nrm);
+            if ((c & 15) == 0) myrr[slot + mine] = r;
+            const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(r), __double2loint(r), false, false);
+            const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(r), __double2hiint(r), false, false);
+            // [0]: rows A C A C, [1]: rows B D B D; a 16-lane swap of each with itself leaves one word's r in every lane
+            const auto aclo = __builtin_amdgcn_permlane16_swap(lo[0], lo[0], false, false);
+            const auto achi = __builtin_amdgcn_permlane16_swap(hi[0], hi[0], false, false);
+            const auto bdlo = __builtin_amdgcn_permlane16_swap(lo[1], lo[1], false, false);
+            const auto bdhi = __builtin_amdgcn_permlane16_swap(hi[1], hi[1], false, false);
+            const double rA = __hiloint2double(achi[0], aclo[0]), rC = __hiloint2double(achi[1], aclo[1]);
+            const double rB = __hiloint2double(bdhi[0], bdlo[0]), rD = __hiloint2double(bdhi[1], bdlo[1]);
 #pragma unroll
-        for (int i = 0; i < RWL; i += 2) {
-            word_pair(B[i], B[i + 1], i);
-            __builtin_amdgcn_sched_barrier(0);                // one pair's chains at a time (registers)
-        }
+            for (int j = 0; j < KRL; ++j) q[j] = fma(rA, rowA[j], q[j]);
 #pragma unroll
-        for (int t = 0; t < TWL; t += 2) {
-            double rowA[KRL], rowB[KRL];
+            for (int j = 0; j < KRL; ++j) q[j] = fma(rB, rowB[j], q[j]);
+#pragma unroll
+            for (int j = 0; j < KRL; ++j) q[j] = fma(rC, rowC[j], q[j]);
+#pragma unroll
+            for (int j = 0; j < KRL; ++j) q[j] = fma(rD, rowD[j], q[j]);
+        };
+        auto lds_row = [&](int t, double (&row)[KRL]) {
 #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
-                const double2 v2 = myrows[t * (KT / 2) + 64 * jj], w2 = myrows[(t + 1) * (KT / 2) + 64 * jj];
-                rowA[2 * jj] = v2.x;
-                rowA[2 * jj + 1] = v2.y;
-                rowB[2 * jj] = w2.x;
-                rowB[2 * jj + 1] = w2.y;
+                const double2 v2 = myrows[t * (KT / 2) + 64 * jj];
+                row[2 * jj] = v2.x;
+                row[2 * jj + 1] = v2.y;
             }
-            word_pair(rowA, rowB, RWL + t);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        static_for<(RWL + TWL) / 4>([&](auto idx) {
+            constexpr int i = 4 * decltype(idx)::value;       // slots i .. i + 3: registers while i + x < RWL, LDS rows beyond
+            if constexpr (i + 4 <= RWL) {
+                word_quad(B[i], B[i + 1], B[i + 2], B[i + 3], i);
+            } else if constexpr (i >= RWL) {
+                double r0[KRL], r1[KRL], r2[KRL], r3[KRL];
+                lds_row(i - RWL, r0); lds_row(i + 1 - RWL, r1); lds_row(i + 2 - RWL, r2); lds_row(i + 3 - RWL, r3);
+                word_quad(r0, r1, r2, r3, i);
+            } else {
+                static_assert(i + 4 <= RWL || i >= RWL || i + 2 == RWL, "two register words + two LDS rows");
+                double r2[KRL], r3[KRL];
+                lds_row(0, r2); lds_row(1, r3);
+                word_quad(B[i], B[i + 1], r2, r3, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);                // one group's chains at a time (registers)
+        });
         if (NS > 0) {
             // (requested here, not before the on-chip words: with the buffers live across those the kernel
             //  spills - and a spilled in-flight buffer would be stored before its data lands)
@@ -347,9 +389,9 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
             tq[2 * jj] = t2.x;
             tq[2 * jj + 1] = t2.y;
         }
-        const double2* gtable = reinterpret_cast<const double2*>(p.expElog_elog);
+        const char* gtable = reinterpret_cast<const char*>(reinterpret_cast<const double2*>(p.expElog_elog) + c);
         for (int s = 0; s < S; ++s) {
-            const double2* row = gtable + (size_t)myids[s] * ldk2 + c;
+            const double2* row = reinterpret_cast<const double2*>(gtable + myoff[s]);
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
@@ -366,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
         if (n < N) {
             const double cnt = mycnt[s], r = myrr[s];
             term3 = fma(cnt, log(cnt) - log(r), term3);    // c_n log(normaliser_n), normaliser = c_n / r_n
-            if (p.heldout) shift_term = fma(cnt, p.shift[myids[s]], shift_term);
+            if (p.heldout) shift_term = fma(cnt, p.shift[p.term_id[lo + n]], shift_term);
             else p.rfinal[lo + n] = r;
         }
     }

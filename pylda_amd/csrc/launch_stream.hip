@@ -26,7 +26,7 @@ int launch_qfuse(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 #ifndef PYLDA_QF4_TWL
 #define PYLDA_QF4_TWL 2
 #endif
-    return ctx->ldk == 512 ? launch_qfuse_np<4, PYLDA_QF4_RWL, PYLDA_QF4_TWL>(ctx, p, L) : launch_qfuse_np<3, 8, 2>(ctx, p, L);
+    return ctx->ldk == 512 ? launch_qfuse_np<4, PYLDA_QF4_RWL, PYLDA_QF4_TWL>(ctx, p, L) : launch_qfuse_np<3, 8, 4>(ctx, p, L);
 }
 
 template <int NP>

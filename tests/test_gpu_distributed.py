@@ -241,26 +241,58 @@ def test_bench_launches_its_own_ranks(tmp_path):
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--docs", "3000",
-                          "--extra-docs", "4000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--docs", "4000",
+                          "--extra-docs", "3000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # ONE JSON line, from rank 0
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak"
-    assert rec["config"]["docs_total"] == 6000 and rec["config"]["docs_per_gpu"] == 3000
+    # top level: cfg 4, the corpus of the scaling curve, sharded over the ranks (strong scaling)
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "strong"
+    assert rec["config"]["docs_total"] == 4000 and rec["config"]["docs_per_gpu"] == 2000 and rec["config"]["K"] == 256
     assert rec["value"] > 0 and rec["roofline"]["kernel_ms_documents"] > 0 and rec["roofline"]["kernel_ms_sstats"] > 0
-    assert abs(rec["value"] - 6000 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
-    sub = rec["synth1m"]
-    assert sub["n_gpus"] == 2 and sub["scaling"] == "strong" and sub["config"]["docs_total"] == 4000
-    assert sum(c["documents"] for c in sub["roofline"]["launch_classes"]) == sub["config"]["docs_per_gpu"]
+    assert abs(rec["value"] - 4000 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
+    assert sum(c["documents"] for c in rec["roofline"]["launch_classes"]) == rec["config"]["docs_per_gpu"]
+    sub = rec["synth100k"]
+    assert sub["n_gpus"] == 2 and sub["scaling"] == "weak" and sub["config"]["docs_total"] == 6000
+    assert sum(c["documents"] for c in sub["roofline"]["launch_classes"]) == sub["config"]["docs_per_gpu"] == 3000
     # cfg 2 and cfg 5 ride along at every N, documents sharded over the ranks; the K = 500 trace is asserted inside
     assert rec["ap_k10"]["n_gpus"] == 2 and rec["ap_k10"]["iters_equal_fraction"] == 1.0
     assert rec["ap_k10"]["max_rel_ll_delta_vs_reference"] < 1e-9
     nips = rec["nips_k500"]
     assert nips["n_gpus"] == 2 and nips["iterations"] == 50 and nips["joint_trace_max_rel_delta"] < 1e-8
     assert nips["heldout_rel_delta"] < 1e-8
+
+
+def test_bench_rehearsal_of_the_eight_rank_run(tmp_path):
+    """The command the driver's 8-GPU run executes, end to end on this box's one GPU (`--share-gpu`: gloo instead of
+    RCCL, everything else as at N = 8): eight chunk-aligned shards of the cfg 4 generator, eight shards of cfg 3,
+    associated-press in eight nnz-balanced ranges of ~250 documents, nips.88-05 K = 500 in eight ranges of ~280 with
+    the reference's 50-iteration trace asserted, max-over-ranks timing and the checksum reductions."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--docs", "200000",
+                          "--extra-docs", "5000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "strong" and rec["config"]["parallelism"] == "dp8"
+    assert rec["config"]["docs_total"] == 200000 and rec["config"]["docs_per_gpu"] == 25000      # whole 25k-document chunks
+    assert abs(rec["config"]["nnz_imbalance"]) < 0.01
+    assert abs(rec["value"] - 200000 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
+    assert "shard_proxy" not in rec                                  # (a single-GPU model: N = 1 only)
+    sub = rec["synth100k"]
+    assert sub["n_gpus"] == 8 and sub["config"]["docs_total"] == 40000 and sub["config"]["docs_per_gpu"] == 5000
+    assert rec["ap_k10"]["n_gpus"] == 8 and rec["ap_k10"]["iters_equal_fraction"] == 1.0
+    assert rec["ap_k10"]["max_rel_ll_delta_vs_reference"] < 1e-9
+    nips = rec["nips_k500"]
+    assert nips["n_gpus"] == 8 and nips["iterations"] == 50 and nips["joint_trace_max_rel_delta"] < 1e-8
+    assert 270 <= nips["config"]["docs_rank0"] <= 290 and nips["heldout_rel_delta"] < 1e-8
 
 
 def test_c_abi_allreduce_world_of_one(ap_train):

@@ -241,6 +241,30 @@ def test_traffic_record_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     value, note = bench.traffic_record("synth100k")
     assert value is None and "STALE" in note
     assert bench.traffic_record("nips") == (None, None) and bench.traffic_record(None) == (None, None)
+    # host translation units are not kernel sources: an edit to the launcher (round 4: a test hook in estep_api.hip)
+    # must not stale the committed traffic figure; an edit to any device header must
+    (tmp_path / "pylda_amd" / "csrc" / "estep_x.h").write_text("// kernel\n")
+    assert bench.traffic_record("synth100k")[0] == 123
+    for host_unit in ("estep_api.hip", "sstats_gather.hip", "plan.hip", "sstats_plan.cpp", "ingest.cpp"):
+        (tmp_path / "pylda_amd" / "csrc" / host_unit).write_text("// host code, edited\n")
+        assert bench.traffic_record("synth100k")[0] == 123, host_unit
+    for device_header in ("sstats_sweep.h", "doc_terms.h", "special_device.h", "estep_common.h"):
+        (tmp_path / "pylda_amd" / "csrc" / device_header).write_text("// device code\n")
+        assert bench.traffic_record("synth100k")[0] is None, device_header
+        (tmp_path / "pylda_amd" / "csrc" / device_header).unlink()
+    # ... and the real tree: every file the hash covers is a header, none a translation unit
+    import os
+    real = os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "pylda_amd", "csrc")
+    touched = tmp_path / "copy"
+    import shutil
+    shutil.copytree(real, touched)
+    base = bench.kernel_source_hash(str(touched))
+    with open(touched / "estep_api.hip", "a") as fh:
+        fh.write("// a test hook\n")
+    assert bench.kernel_source_hash(str(touched)) == base
+    with open(touched / "estep_quad.h", "a") as fh:
+        fh.write("// a kernel edit\n")
+    assert bench.kernel_source_hash(str(touched)) != base
 
 
 def test_launch_train_flags_and_launcher_command():
