@@ -278,7 +278,11 @@ int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
  *                    0 never, 1 (default) where the partial rows of the dispatch-paced gather would exceed their
  *                    budget, 2 whenever the gather is blocked;
  *   "gather_round_mb" budget of the gather's partial rows (one per (term, document block) pair) in MiB, 0 = 4 GiB:
- *                    beyond it the gather runs in rounds over term ranges that reuse the rows;
+ *                    beyond it the statistics pass is the sweep (gather_sweep = 1) or the gather runs in rounds over term
+ *                    ranges that reuse the rows.  The sweep-or-gather decision is taken against this figure only; the rounds
+ *                    are additionally capped by a quarter of the device memory free at the time (more, smaller rounds on
+ *                    a busy device) - which changes no bit of the result: partial rows are summed in segment order and the
+ *                    likelihood's entropy partials are laid out by blocks of the whole table, whatever the rounds;
  *   "wide_postings"  1: 64-bit CSR positions in the postings whatever the corpus size (automatic from 2^31 pairs);
  *   "sweep_xcd"      1 (default): the sweep's rendezvous per XCD (the 32 workgroups that share an L2), 0: chip-wide;
  *   "sweep_spin"     polls of a rendezvous before a workgroup goes on alone (pacing only, never correctness);
@@ -287,7 +291,8 @@ int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
  *   "launch_order"   1 (default): launch classes with the fewest documents go out first, 0: longest documents first
  *                    (scheduling options never change a bit of the results);
  *   "slab_uber"      1 (default): the slab launch classes of a small corpus go out as one dispatch;
- *   "quad" (1: documents of <= 224 distinct terms at 64 < K <= 256 run on the quad kernel), "quilt_odd",
+ *   "quad" (1: documents of <= 224 distinct terms at 64 < K <= 256 run on the quad kernel), "quad_stream" (1: ... and
+ *   those of 225-256 terms too, with word slots streamed from the table), "quilt_odd",
  *   "quilt12", "lds_pad"  A/B switches of kernel geometry ("Tried and measured"). */
 int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value);
 

@@ -4,8 +4,10 @@ This is the only place Python touches the native library.  There is no CPU
 fallback anywhere in pylda_amd: if the shared library is missing, or no HIP
 device is visible, the failure is raised here, loudly.
 """
+import collections
 import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -166,19 +168,27 @@ class _PinnedBlock(object):
 # Idle page-locked blocks, oldest first: (pointer, nbytes).  The pool is bounded by BYTES, not by count per size - a
 # long-running process that asks for many different shapes (inference() on corpora of varying D) must not accumulate
 # page-locked memory - and arrays above _PINNED_MAX_ARRAY (the 2 GB gamma of a 1M-document corpus) are never pinned.
-_pinned_idle = []
+# __del__ of a block may run at any garbage-collection point, on any thread, also while pinned_empty() scans the list:
+# one re-entrant lock around every access (re-entrant: a collection triggered inside the locked region may release a
+# block on the same thread).
+_pinned_idle = collections.deque()
 _pinned_idle_bytes = 0
+_pinned_lock = threading.RLock()
 _PINNED_POOL_CAP = 1 << 30          # idle page-locked bytes kept for reuse (least recently released go first)
 _PINNED_MAX_ARRAY = 1 << 29         # larger arrays come from ordinary (pageable) memory
 
 
 def _pinned_release(ptr, nbytes):
     global _pinned_idle_bytes
-    _pinned_idle.append((ptr, nbytes))
-    _pinned_idle_bytes += nbytes
-    while _pinned_idle and _pinned_idle_bytes > _PINNED_POOL_CAP:
-        old_ptr, old_bytes = _pinned_idle.pop(0)
-        _pinned_idle_bytes -= old_bytes
+    evicted = []
+    with _pinned_lock:
+        _pinned_idle.append((ptr, nbytes))
+        _pinned_idle_bytes += nbytes
+        while _pinned_idle and _pinned_idle_bytes > _PINNED_POOL_CAP:
+            old_ptr, old_bytes = _pinned_idle.popleft()
+            _pinned_idle_bytes -= old_bytes
+            evicted.append(old_ptr)
+    for old_ptr in evicted:                 # (the driver call outside the lock)
         if _lib is not None:
             _lib.pylda_host_free(_vp(old_ptr))
 
@@ -199,11 +209,13 @@ def pinned_empty(shape, dtype=np.float64):
     if nbytes == 0 or nbytes > _PINNED_MAX_ARRAY:
         return np.empty(shape, dtype=dtype)
     ptr = None
-    for i in range(len(_pinned_idle) - 1, -1, -1):      # most recently released block of exactly this size
-        if _pinned_idle[i][1] == nbytes:
-            ptr = _pinned_idle.pop(i)[0]
-            _pinned_idle_bytes -= nbytes
-            break
+    with _pinned_lock:
+        for i in range(len(_pinned_idle) - 1, -1, -1):      # most recently released block of exactly this size
+            if _pinned_idle[i][1] == nbytes:
+                ptr = _pinned_idle[i][0]
+                del _pinned_idle[i]
+                _pinned_idle_bytes -= nbytes
+                break
     if ptr is None:
         handle = _vp()
         rc = lib.pylda_host_alloc(nbytes, ctypes.byref(handle))

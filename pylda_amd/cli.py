@@ -54,6 +54,15 @@ def _lines(path):
         return [line.strip().lower() for line in stream]
 
 
+def _phase(label, since):
+    """PYLDA_TIMING=1: wall time of the start-up phases on stderr (every rank)."""
+    import time
+    now = time.perf_counter()
+    if os.environ.get("PYLDA_TIMING"):
+        sys.stderr.write("[pylda timing] rank %s %-40s %8.1f ms\n" % (os.environ.get("RANK", "0"), label, (now - since) * 1e3))
+    return now
+
+
 def _banner(pairs):
     print(RULE)
     for key, value in pairs:
@@ -106,12 +115,16 @@ def train_main(argv=None):
     _banner((("output_directory", run_dir),) + settings[:1] + settings[1:])
 
     from pylda_amd.variational_bayes import VariationalBayes
+    import time
     engine = VariationalBayes(device=device, process_group=group)
     if seed is not None:
         numpy.random.seed(int(seed))
-    engine._initialize(documents, vocabulary, topics, prior_topics, prior_words)
-    if group is not None:
-        _shard_engine(engine, group, rank, world)
+    started = time.perf_counter()
+    if group is None:
+        engine._initialize(documents, vocabulary, topics, prior_topics, prior_words)
+    else:
+        _initialize_shard(engine, documents, vocabulary, topics, prior_topics, prior_words, rank, world)
+    _phase("parse + initial eta", started)
     for _ in range(opt.training_iterations):
         engine.learning()
         if engine._counter % opt.snapshot_interval == 0:
@@ -119,7 +132,7 @@ def train_main(argv=None):
             if rank == 0:
                 whole.export_beta("%sexp_beta-%d" % (run_dir, engine._counter))
                 whole.export_gamma("%sexp_gamma-%d" % (run_dir, engine._counter))
-    whole = _whole_model(engine, group, rank, world)
+    whole = _whole_model(engine, group, rank, world, with_corpus=True)
     if rank == 0:
         with open(os.path.join(run_dir, "model-%d" % engine._counter), "wb") as out:
             pickle.dump(whole, out)
@@ -148,12 +161,16 @@ def _join_ranks(opt):
         # started under torchrun (or another launcher) without --gpus: WORLD_SIZE ranks that each trained the whole
         # corpus on --device and wrote the same run directory would be silently wrong - the launcher's size it is
         opt.gpus = world
+    if "WORLD_SIZE" in os.environ and opt.gpus != world:
+        # (also --gpus 4 under a launcher of ONE rank: a quarter of the machine silently doing all of the work)
+        raise SystemExit("--gpus %d does not match the launcher's WORLD_SIZE %d" % (opt.gpus, world))
     if opt.gpus <= 1 or world <= 1:
         return 0, 1, opt.device, None
-    if opt.gpus != world:
-        raise SystemExit("--gpus %d does not match the launcher's WORLD_SIZE %d" % (opt.gpus, world))
     import torch
     import torch.distributed as dist
+    if "RANK" not in os.environ:
+        raise SystemExit("WORLD_SIZE=%d is set but RANK is not: start the ranks with torch.distributed.run (or pass "
+                         "--gpus N and let launch_train start them)" % world)
     rank = int(os.environ["RANK"])
     device = 0 if opt.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(device)
@@ -175,41 +192,90 @@ def _host_group():
     return _host_group.group
 
 
-def _shard_engine(engine, group, rank, world):
-    """Every rank parsed the whole corpus and drew its own eta (:95, unseeded in the reference): keep rank 0's
-    draw everywhere, and this rank's contiguous nnz-balanced range of the documents."""
+def _line_ranges(documents, world):
+    """Contiguous ranges of the corpus' lines, one per rank, balanced by BYTES (the proxy for distinct terms that is
+    known before parsing; SURVEY 8e balances by nnz): world + 1 line offsets, the same on every rank."""
+    weight = numpy.fromiter((len(line) + 1 for line in documents), dtype=numpy.int64, count=len(documents))
+    ends = numpy.cumsum(weight)
+    total = int(ends[-1]) if len(ends) else 0
+    bounds = [0]
+    for r in range(1, world):
+        at = int(numpy.searchsorted(ends, total * r / world, side="left"))
+        bounds.append(min(max(at, bounds[-1]), len(documents)))
+    bounds.append(len(documents))
+    return bounds
+
+
+def _initialize_shard(engine, documents, vocabulary, topics, prior_topics, prior_words, rank, world):
+    """variational_bayes.py:82-96 on one rank of several: this rank parses ITS lines only (round 4 parsed the whole
+    corpus on every rank and threw 1 - 1/N of it away), rank 0 alone draws eta (:95, the process' first draw from
+    numpy's global stream - the reference's own initial state under a seed) and every rank receives it."""
     import torch
     import torch.distributed as dist
-    from pylda_amd.corpus import shard_csr
-    eta = torch.from_numpy(numpy.ascontiguousarray(engine._eta))
+    from pylda_amd.inferencer import Inferencer
+    lo, hi = _line_ranges(documents, world)[rank:rank + 2]
+    Inferencer._initialize(engine, vocabulary, topics, prior_topics, prior_words)
+    engine._parsed_corpus = None
+    engine._train_csr = engine.parse_to_csr(documents[lo:hi])
+    engine._number_of_documents = len(engine._train_csr[0]) - 1
+    engine._gamma = None
+    engine._gamma_init_pending = True
+    shape = (engine._number_of_topics, engine._number_of_types)
+    eta = torch.from_numpy(numpy.random.gamma(100., 1. / 100., shape)) if rank == 0 else torch.empty(shape, dtype=torch.float64)
     dist.broadcast(eta, src=0, group=_host_group())
     engine._eta = eta.numpy()
-    engine._whole_csr = engine._train_csr
-    doc_ptr, term_id, term_ct, (lo, hi) = shard_csr(*engine._train_csr, world, rank)
-    engine._train_csr = (doc_ptr, term_id, term_ct)
-    engine._parsed_lists = None
-    engine._number_of_documents = hi - lo
+    engine._ctx = None
     engine._train_corpus = None
 
 
-def _whole_model(engine, group, rank, world):
+def _gather_rows(local, rank, world):
+    """The ranks' arrays (equal trailing shape) one after the other in a pre-allocated array on rank 0 - tensor
+    receives straight into its slices, no pickling (gamma is 2 GB at cfg 4); None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    group = _host_group()
+    local = numpy.ascontiguousarray(local)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64), group=group)
+    sizes = [int(t) for t in sizes]
+    if rank != 0:
+        if local.shape[0]:
+            dist.send(torch.from_numpy(local), dst=0, group=group)
+        return None
+    whole = numpy.empty((sum(sizes),) + local.shape[1:], dtype=local.dtype)
+    whole[:sizes[0]] = local
+    at = sizes[0]
+    for src in range(1, world):
+        if sizes[src]:
+            dist.recv(torch.from_numpy(whole[at:at + sizes[src]]), src=src, group=group)
+        at += sizes[src]
+    return whole
+
+
+def _whole_model(engine, group, rank, world, with_corpus=False):
     """The engine the exporters and the snapshot pickle see: at one rank the engine itself; at several, on rank 0, a
-    copy that holds the WHOLE corpus and the gamma rows of every rank in document order (the shards are contiguous)."""
+    copy that holds the gamma rows of every rank in document order (the shards are contiguous) and - for the snapshot,
+    which like the reference's pickle carries the parsed corpus - the whole corpus, gathered once."""
     if group is None:
         return engine
     import copy
-    import torch.distributed as dist
-    rows = [None] * world if rank == 0 else None
-    dist.gather_object(numpy.asarray(engine._gamma), rows, dst=0, group=_host_group())
+    gamma = _gather_rows(numpy.asarray(engine._gamma), rank, world)
+    corpus = None
+    if with_corpus:
+        doc_ptr, term_id, term_ct = engine._train_csr
+        lengths = _gather_rows(numpy.diff(numpy.asarray(doc_ptr, dtype=numpy.int64)), rank, world)
+        ids = _gather_rows(numpy.asarray(term_id, dtype=numpy.int32), rank, world)
+        cts = _gather_rows(numpy.asarray(term_ct, dtype=numpy.int32), rank, world)
+        if rank == 0:
+            corpus = (numpy.concatenate([numpy.zeros(1, numpy.int64), numpy.cumsum(lengths)]), ids, cts)
     if rank != 0:
         return None
     whole = copy.copy(engine)
     whole.__dict__.update(engine.__getstate__())          # host copies only, no device handles
-    whole._gamma_host = numpy.concatenate(rows, axis=0)
-    whole._train_csr = engine._whole_csr
+    whole._gamma_host = gamma
+    whole._train_csr = corpus
     whole._parsed_lists = None
-    whole._number_of_documents = len(engine._whole_csr[0]) - 1
-    whole.__dict__.pop("_whole_csr", None)
+    whole._number_of_documents = gamma.shape[0]
     return whole
 
 

@@ -85,11 +85,7 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     ctx->device = device;
     ctx->K = K;
     ctx->V = V;
-    // table stride: K rounded up to 16 / 32 / 64 / 128 / 256 (the strides the register kernels are built for: 129-192
-    // topics run the stride-256 kernels), from 257 to 1024 to a multiple of 128 (the fused streaming kernels' rows are
-    // 64 lanes x 16-byte pieces), beyond to a multiple of 64
-    ctx->ldk = K <= 16 ? 16 : K <= 32 ? 32 : K <= 64 ? 64 : K <= 128 ? 128 : K <= 256 ? 256
-             : K <= 1024 ? (K + 127) / 128 * 128 : (K + 63) / 64 * 64;
+    ctx->ldk = table_stride_for(K);
     auto bail = [&](int code) {
         g_create_error = ctx->err;
         pylda_destroy(ctx);

@@ -19,9 +19,10 @@
 
 namespace pylda {
 
-// It is launched per LAUNCH CLASS, right behind the class' document kernel on the same stream (p.order = the class'
-// documents, `count` of them): the wavefronts then run in the tail of that kernel and beside the other classes'
-// kernels - on CUs a draining class has freed - instead of as a serial pass after the last document kernel.
+// ONE launch per E-step over all D documents (p.order = nullptr, count = D), behind the join of the launch classes:
+// on an auxiliary stream beside the dispatch-paced statistics gather (fp64-bound next to L2-bound), in front of the
+// persistent sweep on the main stream (the sweep needs every CU to itself).  A launch per class right behind the
+// class' kernel was measured and not kept.  (p.order is honoured for callers that pass a document list.)
 __global__ __launch_bounds__(256) void doc_terms_kernel(EstepParams p, int64_t count)
 {
     const int lane = threadIdx.x & (kWave - 1);

@@ -340,16 +340,21 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         leaves_terms = leaves_terms || L.variant == kQuad || L.variant == kQuilt || L.variant == kQgroup || L.variant == kQfuse || L.variant == kQfusek;
     const bool terms_pass = !heldout && !p.want_doc_ll && c->D > 0 && leaves_terms && !ctx->force_logspace;
     const bool terms_beside_gather = terms_pass && c->have_postings && !c->sweep && ctx->terms_overlap;
+    bool terms_forked = false;          // the pass runs on aux_stream[0]: the main stream joins it inside the statistics bracket
     if (terms_pass) {
         p.order = nullptr;
         hipStream_t st = ctx->stream;
-        if (terms_beside_gather) {
+        // (a failure to fork keeps the pass on the main stream: no exit of this function leaves work on the auxiliary
+        //  stream that the main stream does not wait for)
+        if (terms_beside_gather && hipEventRecord(ctx->fork_event, ctx->stream) == hipSuccess &&
+            hipStreamWaitEvent(ctx->aux_stream[0], ctx->fork_event, 0) == hipSuccess)
             st = ctx->aux_stream[0];
-            HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->fork_event, 0));
-        }
         hipLaunchKernelGGL(doc_terms_kernel, dim3((unsigned)((c->D + 3) / 4)), dim3(256), 0, st, p, c->D);
-        if (terms_beside_gather) HIP_TRY(ctx, hipEventRecord(ctx->join_event[0], st));
+        terms_forked = st != ctx->stream;
+        if (terms_forked && hipEventRecord(ctx->join_event[0], st) != hipSuccess) {
+            (void)hipStreamSynchronize(st);         // cannot order by event: order by the host, once
+            terms_forked = false;
+        }
     }
     close_bracket(doc_bracket, ctx->stream);
     if (ctx->profiling) ctx->estep_calls += 1;
@@ -364,7 +369,9 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         }
         const int ss_bracket = open_bracket(-2, ctx->stream);
         rc = enqueue_sstats_gather(ctx, c);
-        if (terms_beside_gather) (void)hipStreamWaitEvent(ctx->stream, ctx->join_event[0], 0);      // (inside the bracket: the pair's wall time)
+        // (inside the bracket: kernel_time()'s `statistics` figure is the wall time of the PAIR gather + document terms
+        //  whenever the pass is forked - bench.py's roofline adds documents + statistics, so nothing is lost or counted twice)
+        if (terms_forked) (void)hipStreamWaitEvent(ctx->stream, ctx->join_event[0], 0);
         close_bracket(ss_bracket, ctx->stream);
         if (rc != PYLDA_OK) return rc;
     }

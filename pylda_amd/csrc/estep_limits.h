@@ -1,7 +1,12 @@
 // Sizes and small parameter blocks that BOTH the kernels and the host-side planner need (the kernel headers define
 // __global__ functions and can be included by one translation unit each; this header by all of them).
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#elif !defined(__host__)        // the planner alone under g++ (host_plan.cpp, sanitizer build)
+#define __host__
+#define __device__
+#endif
 #include <stddef.h>
 #include <stdint.h>
 

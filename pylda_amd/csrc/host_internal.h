@@ -2,7 +2,8 @@
 // and the host-side functions its translation units share.  Nothing here is part of the ABI.
 //
 //   context.hip        handles, options, model tables in and out, host memory, marks, RCCL glue, test hooks
-//   plan.hip           launch classes: kernel variant and geometry per distinct-term count (host code only)
+//   host_plan.cpp      the planner: launch classes, segment cut, rounds, sweep dealing - pure host functions, no HIP
+//   plan.hip           the planner's configuration from the context; pylda_corpus_plan / pylda_corpus_layout
 //   launch_small.hip   document kernels, generic / slab / quilt families
 //   launch_quad.hip    ... the register + LDS tile kernel (strides 128 / 256)
 //   launch_stream.hip  ... the fused streaming families (qfuse, qfusek, qgroup)
@@ -30,42 +31,13 @@
 #include "comm.h"
 #include "estep_common.h"
 #include "estep_limits.h"
+#include "host_plan.h"
 #include "postings.h"
 
 using namespace pylda;
 
 namespace pylda_host __attribute__((visibility("hidden"))) {
-
-enum Variant : int {
-    kGeneric64 = 0,    // 1 wavefront / document, tile in LDS
-    kGeneric256 = 1,   // 4 wavefronts / document, tile in LDS
-    kGeneric512 = 2,   // 8 wavefronts / document, tile in LDS (up to the whole 160 KiB)
-    kGenericGlobal = 3, // tile larger than LDS: rows re-read from the table
-    kSlab = 4,          // tile in registers, word-major lanes (estep_slab.h)
-    kRetired5 = 5,      // (the topic-major column kernel of round 1: measured 2x slower than the quilt layout, removed)
-    kQuilt = 6,         // tile in registers, 4 x 16 word-group x topic lanes (estep_quilt.h)
-    kRetired7 = 7,      // (rounds 1-2: two-pass streaming, hybrid and wide tiered kernels - their streamed tier was read
-    kRetired8 = 8,      //  twice per iteration; replaced by the quad kernel's streamed slots and estep_qgroup.h)
-    kQgroup = 9,        // table stride 128 / 256, more than 256 terms: rows streamed once per iteration, fused per word group (estep_qgroup.h)
-    kQuad = 10,         // 16 word groups / document, tile in registers + LDS rows (estep_quad.h)
-    kQfuse = 11,        // table stride 512: rows streamed ONCE per iteration, normaliser and topic sums fused (estep_qfuse.h)
-    kGenericHuge = 12,  // a document too long even for its per-term scalars in LDS: those in global memory too (estep_generic.h MODE 2)
-    kQfusek = 13,       // table stride 640 .. 1024: every row streamed once per iteration, fused (estep_qfusek.h)
-    kVariantLast = kQfusek
-};
-
-struct Launch {
-    int variant;
-    int64_t first;   // offset into the sorted order
-    int64_t count;   // documents (= workgroups)
-    int n_cap;       // largest distinct-term count in the launch
-    int tile_stride;
-    size_t lds_bytes;
-    int rn;          // slab kernels: words per lane
-    int rk;          // slab kernels: topics per wavefront
-};
-
-
+using namespace pylda_plan;     // Variant, Launch, the planner (host_plan.h: HIP-free, sanitizer-tested)
 }  // namespace pylda_host
 
 using namespace pylda_host;
@@ -130,7 +102,8 @@ struct pylda_ctx {
     int sweep_spin = 4000;          // polls of a rendezvous of the sweep before a workgroup goes on alone
     int gather_sweep = 1;           // the persistent sweep (sstats_sweep.h) at stride 128 / 256: 0 never, 1 when the partial rows of the
                                     // dispatch-paced gather would exceed their budget (rounds), 2 whenever the gather is blocked
-    int gather_round_mb = 0;        // budget of the gather's partial rows per round, MiB (0: 4 GiB)
+    int gather_round_mb = 0;        // budget of the gather's partial rows per round, MiB (0: 4 GiB for the sweep-or-gather decision;
+                                    // the rounds themselves are also capped by a quarter of the free device memory)
     int launch_order = 1;           // 0: launch classes in plan order (longest documents first), 1: fewest documents first (cfg 3: -0.5 %)
     int terms_overlap = 1;          // doc_terms_kernel on an auxiliary stream beside the dispatch-paced statistics gather
     int slab_uber = 1;              // small corpora: all slab launch classes in one dispatch
@@ -188,7 +161,7 @@ struct pylda_corpus {
     // The gather runs in ROUNDS over contiguous term ranges that share one set of partial rows (a (term, block)
     // pair costs a row: 45 GB at cfg 4 in one go - and a second for the allocation alone): gather round r, finalize
     // its terms, reuse the rows.  One round unless the rows would exceed the budget.
-    struct Round { int64_t seg_lo, seg_hi; int w_first, n_words; int64_t slot_lo, slot_count; int64_t ent_first, ent_blocks; };
+    using Round = pylda_plan::Round;
     std::vector<Round> rounds;
     int64_t partial_rows = 0, ent_blocks = 0;
     // ... or the persistent sweep (sstats_sweep.h): no partial rows at all
@@ -254,7 +227,7 @@ struct PhaseTimer {
 };
 
 // ---- plan.hip ----
-inline int tile_stride_for(int K) { return K | 1; }   // LDS tile row stride of the generic kernels: odd => conflict-free ds_read_b64 along words
+PlanConfig plan_config(const pylda_ctx* ctx);
 void build_plan(pylda_corpus* c);
 int slab_uber_from(const pylda_ctx* ctx, const pylda_corpus* c);    // first class of the one-dispatch slab group, or -1
 

@@ -6,21 +6,6 @@
 
 namespace pylda_host {
 
-// Geometry of the persistent sweep (sstats_sweep.h) for V terms: terms per wavefront and wavefronts per workgroup (one
-// workgroup per CU) such that the fewest passes over the document blocks cover all terms.
-struct SweepGeom { int T, WPB, passes; };
-static SweepGeom sweep_geom_for(const pylda_ctx* ctx, int V)
-{
-    const int64_t cus = ctx->num_cu;
-    auto passes = [&](int T, int WPB) { return (int)((V + cus * WPB * T - 1) / (cus * WPB * T)); };
-    if (ctx->ldk == 128) {
-        if (passes(12, 16) == 1) return {12, 16, 1};
-        return {16, 16, passes(16, 16)};
-    }
-    const int a = passes(8, 16), b = passes(12, 12);       // stride 256: 8 VGPRs per term
-    return b < a ? SweepGeom{12, 12, b} : SweepGeom{8, 16, a};
-}
-
 #define PYLDA_SWEEP_DISPATCH(ctx, c, DO)                                                             \
     do {                                                                                             \
         const int t_ = (c)->sweep_terms, w_ = (c)->sweep_wpb;                                        \
@@ -30,335 +15,200 @@ static SweepGeom sweep_geom_for(const pylda_ctx* ctx, int V)
         else { if ((c)->wide_pos) { DO(4, 8, 16, int64_t); } else { DO(4, 8, 16, int32_t); } }                                \
     } while (0)
 
-// One host thread's share of the segment cut (build_postings): the segments of a contiguous range of terms.
-struct CutPiece {
-    std::vector<int64_t> begin, end, per_word;
-    std::vector<int32_t> block, per_block;      // per_block[b]: this piece's segments in document block b
-    int v0 = 0;
-    int64_t base = 0;                           // index of its first segment in the whole list
-};
+static_assert(kGatherSegment == kSegment && kSweepSegmentCap == kSweepSegment, "the planner cuts what the kernels walk");
 
-template <typename F>
-void run_on_threads(int nthreads, F&& fn)
+namespace {
+
+GatherConfig gather_config(const pylda_ctx* ctx, const pylda_corpus* c)
 {
-    std::vector<std::thread> workers;
-    for (int t = 1; t < nthreads; ++t) workers.emplace_back(fn, t);
-    fn(0);
-    for (auto& w : workers) w.join();
+    GatherConfig g;
+    g.V = ctx->V;
+    g.ldk = ctx->ldk;
+    g.num_cu = ctx->num_cu;
+    g.D = c->D;
+    g.nnz = c->nnz;
+    g.gather_rows = ctx->gather_rows;
+    g.gather_blocks = ctx->gather_blocks;
+    g.gather_sweep = ctx->gather_sweep;
+    g.gather_round_mb = ctx->gather_round_mb;
+    return g;
 }
 
-// Postings (CSC) of the corpus, built once, on the first training E-step, on the device (postings.hip):
-// for every word the (document, CSR position) pairs in document order, cut into segments.
+// every exit of build_postings that is not its last line leaves the corpus without postings AND without their arrays: a
+// retry (the next training E-step) starts from scratch instead of leaking nnz * 8 bytes or more per attempt
+struct PostingsUndo {
+    pylda_corpus* c;
+    bool keep = false;
+    ~PostingsUndo()
+    {
+        if (keep) return;
+        dev_free(c->d_post_doc);
+        if (c->d_post_pos) (void)hipFree(c->d_post_pos);
+        c->d_post_pos = nullptr;
+        dev_free(c->d_exec_order); dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial);
+        dev_free(c->d_seg_block); dev_free(c->d_term_of); dev_free(c->d_rendezvous);
+        c->sweep = false;
+        c->nseg = 0;
+        c->exec_slots = 0;
+        c->rounds.clear();
+    }
+};
+
+template <typename T>
+int upload(pylda_ctx* ctx, T** dst, const std::vector<T>& src, size_t at_least = 0)
+{
+    const int rc = dev_alloc(ctx, dst, std::max(src.size(), at_least));
+    if (rc != PYLDA_OK) return rc;
+    if (!src.empty() && hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(ctx, PYLDA_ERR_HIP, "postings: H2D copy failed");
+    return PYLDA_OK;
+}
+
+// the CSC index itself, on the device (postings.hip); col_ptr comes back to the host
+int device_postings(pylda_ctx* ctx, pylda_corpus* c, std::vector<int64_t>* col_ptr)
+{
+    const int64_t nnz = c->nnz;
+    c->wide_pos = ctx->wide_postings || nnz > INT32_MAX;
+    int rc = dev_alloc(ctx, &c->d_post_doc, (size_t)nnz);
+    if (rc != PYLDA_OK) return rc;
+    const size_t bytes = (size_t)std::max<int64_t>(nnz, 1) * (c->wide_pos ? sizeof(int64_t) : sizeof(int32_t));
+    const hipError_t ea = hipMalloc(&c->d_post_pos, bytes);
+    if (ea != hipSuccess) {
+        c->d_post_pos = nullptr;
+        return fail(ctx, ea == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, "postings: hipMalloc: %s", hipGetErrorString(ea));
+    }
+    col_ptr->assign((size_t)ctx->V + 1, 0);
+    const char* what = "";
+    const hipError_t e = build_postings_device(ctx->stream, ctx->V, c->D, nnz, c->d_doc_ptr, c->d_term_id, c->d_post_doc,
+                                               c->d_post_pos, c->wide_pos, col_ptr->data(), &what);
+    if (e != hipSuccess)
+        return fail(ctx, e == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return PYLDA_OK;
+}
+
+// the documents of the postings on the host, through a page-locked buffer (0.8 GB at cfg 4: 16 ms instead of the
+// pageable copy's 0.3 s)
+struct PinnedDocs {
+    int32_t* p = nullptr;
+    ~PinnedDocs() { if (p) (void)hipHostFree(p); }
+    int fetch(pylda_ctx* ctx, const pylda_corpus* c)
+    {
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), (size_t)std::max<int64_t>(c->nnz, 1) * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+            p = nullptr;
+            return fail(ctx, PYLDA_ERR_OOM, "postings: page-locked staging buffer");
+        }
+        if (c->nnz > 0 && hipMemcpy(p, c->d_post_doc, (size_t)c->nnz * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(ctx, PYLDA_ERR_HIP, "postings: D2H copy failed");
+        return PYLDA_OK;
+    }
+};
+
+// the persistent sweep: every wavefront owns a few terms, all workgroups walk the document blocks together
+int install_sweep(pylda_ctx* ctx, pylda_corpus* c, const SegmentCut& cut, const std::vector<int64_t>& col_ptr)
+{
+    const int64_t nwaves = (int64_t)ctx->num_cu * c->sweep_wpb;
+    const std::vector<int32_t> term_of = deal_terms(col_ptr.data(), ctx->V, nwaves, c->sweep_terms, c->sweep_passes);
+    std::vector<int32_t> seg_block((size_t)c->nseg);
+    run_on_threads((int)cut.pieces.size(), [&](int t) {
+        std::copy(cut.pieces[(size_t)t].block.begin(), cut.pieces[(size_t)t].block.end(), seg_block.begin() + cut.pieces[(size_t)t].base);
+    });
+    int rc = upload(ctx, &c->d_seg_block, seg_block);
+    if (rc == PYLDA_OK) rc = upload(ctx, &c->d_term_of, term_of);
+    if (rc == PYLDA_OK) rc = dev_alloc(ctx, &c->d_rendezvous, (size_t)kSweepCounters * 32);      // one counter per XCD, a cache line apart
+    dev_free(c->d_entropy_partial);
+    if (rc == PYLDA_OK) rc = dev_alloc(ctx, &c->d_entropy_partial, (size_t)c->sweep_passes * nwaves);
+    if (rc != PYLDA_OK) return rc;
+    c->sweep = true;
+    c->ent_blocks = (int64_t)c->sweep_passes * nwaves;
+    c->partial_rows = 0;
+    return PYLDA_OK;
+}
+
+// the dispatch-paced gather: rounds, their XCD execution order, the partial rows
+int install_rounds(pylda_ctx* ctx, pylda_corpus* c, const RoundPlan& plan)
+{
+    c->rounds = plan.rounds;
+    c->partial_rows = plan.partial_rows;
+    c->ent_blocks = plan.ent_blocks;
+    c->exec_slots = (int64_t)plan.order.size();
+    int rc = PYLDA_OK;
+    if (!plan.order.empty()) rc = upload(ctx, &c->d_exec_order, plan.order);
+    if (rc == PYLDA_OK) rc = dev_alloc(ctx, &c->d_partial, (size_t)c->partial_rows * ctx->ldk);
+    dev_free(c->d_entropy_partial);
+    if (rc == PYLDA_OK) rc = dev_alloc(ctx, &c->d_entropy_partial, (size_t)c->ent_blocks);
+    return rc;
+}
+
+}  // namespace
+
+// Postings (CSC) of the corpus, built once, on the first training E-step, on the device (postings.hip): for every word
+// the (document, CSR position) pairs in document order, cut into segments.  The layout decisions - document blocks,
+// segment cut, sweep or rounds, execution order - are the planner's (host_plan.cpp); this function moves the data.
 int build_postings(pylda_corpus* c)
 {
     if (c->have_postings) return PYLDA_OK;
     pylda_ctx* ctx = c->ctx;
     const int V = ctx->V;
     const int64_t nnz = c->nnz;
-    int rc = PYLDA_OK;
-    auto A = [&](int r) { if (rc == PYLDA_OK) rc = r; };
-    // every exit below that is not the last line leaves the corpus without postings AND without their arrays: a
-    // retry (the next training E-step) starts from scratch instead of leaking nnz * 8 bytes or more per attempt
-    struct Undo {
-        pylda_corpus* c;
-        bool keep = false;
-        ~Undo()
-        {
-            if (keep) return;
-            dev_free(c->d_post_doc);
-            if (c->d_post_pos) (void)hipFree(c->d_post_pos);
-            c->d_post_pos = nullptr;
-            dev_free(c->d_exec_order); dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial);
-            dev_free(c->d_seg_block); dev_free(c->d_term_of); dev_free(c->d_rendezvous);
-            c->sweep = false;
-            c->nseg = 0;
-            c->exec_slots = 0;
-            c->rounds.clear();
-        }
-    } undo{c};
+    PostingsUndo undo{c};
     PhaseTimer timer;
-    c->wide_pos = ctx->wide_postings || nnz > INT32_MAX;
-    A(dev_alloc(ctx, &c->d_post_doc, (size_t)nnz));
-    if (rc == PYLDA_OK) {
-        const size_t bytes = (size_t)std::max<int64_t>(nnz, 1) * (c->wide_pos ? sizeof(int64_t) : sizeof(int32_t));
-        const hipError_t ea = hipMalloc(&c->d_post_pos, bytes);
-        if (ea != hipSuccess) {
-            c->d_post_pos = nullptr;
-            rc = fail(ctx, ea == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, "postings: hipMalloc: %s", hipGetErrorString(ea));
-        }
-    }
+    std::vector<int64_t> col_ptr;
+    int rc = device_postings(ctx, c, &col_ptr);
     if (rc != PYLDA_OK) return rc;
-    std::vector<int64_t> col_ptr((size_t)V + 1, 0);
-    const char* what = "";
-    const hipError_t e = build_postings_device(ctx->stream, V, c->D, nnz, c->d_doc_ptr, c->d_term_id, c->d_post_doc,
-                                               c->d_post_pos, c->wide_pos, col_ptr.data(), &what);
-    if (e != hipSuccess)
-        return fail(ctx, e == hipErrorOutOfMemory ? PYLDA_ERR_OOM : PYLDA_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     timer.lap("postings on the device");
-    std::vector<int64_t> seg_begin, seg_end, word_seg_ptr((size_t)V + 1, 0);
-    seg_begin.reserve((size_t)(nnz / kSegment + V));
-    seg_end.reserve((size_t)(nnz / kSegment + V));
-    // Document-blocked gather (sstats_kernels.h): NB contiguous document blocks whose t rows fit an XCD's L2,
-    // NB a multiple of the 8 XCDs; only for the whole-row kernel, when all of t exceeds one L2 and a
-    // (term, block) pair still holds >= 8 postings on average.
-    int NB = 1;
-    {
-        const double t_bytes = (double)c->D * ctx->ldk * sizeof(double);
-        const bool rows_kernel = ctx->gather_rows >= 1 && (ctx->ldk == 64 || ctx->ldk == 128 || ctx->ldk == 256);
-        const bool bulk_kernel = ctx->gather_rows == 2 && (ctx->ldk == 128 || ctx->ldk == 256);   // (short segments need it)
-        if (ctx->gather_blocks > 1 && rows_kernel && V > 0) {
-            NB = ctx->gather_blocks;                                  // forced (tests, A/B runs)
-        } else if (ctx->gather_blocks < 0 && bulk_kernel && t_bytes > 8.6e6 && V > 0) {
-            // automatic: blocks of about one L2 (cfg 3 sweep: 16 -> 1.78 ms, 24 -> 1.62, 32 -> ~1.8, 64 -> 3.1; unblocked 3.03),
-            // but no more than leave a (term, block) pair 8 postings on average - every pair costs a partial row
-            // (cfg 4, t = 2 GB: 64 blocks 55 ms, 128 53, 256 48, unblocked 65; 240 by this rule); the rows themselves are
-            // budgeted per round below
-            const int by_l2 = std::max(8, 8 * (int)std::lround(t_bytes / (8 * 4.3e6)));
-            const int by_pairs = (int)std::min<double>(1e6, (double)nnz / (8.0 * V)) / 8 * 8;
-            NB = std::min(by_l2, by_pairs);
-            if (NB < 8) NB = 1;
-        }
-    }
-    // budget of the gather's partial rows per round: option gather_round_mb, else 4 GiB but never more than a quarter of
-    // the device memory that is free right now (a shared or nearly full device gets more, smaller rounds instead of an
-    // allocation failure)
-    double round_budget = 4.0 * 1073741824.0;
-    if (ctx->gather_round_mb > 0) {
-        round_budget = (double)ctx->gather_round_mb * 1048576.0;
-    } else {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) round_budget = std::min(round_budget, (double)free_b / 4.0);
-    }
-    // (a) the gather kernel family is fixed here, with the postings: the partial rows, the rounds and seg_lo below are
-    // sized for it, so a later change of the option must not change the kernel that walks them
+
+    const GatherConfig g = gather_config(ctx, c);
+    const int NB = document_blocks(g);
+    // (the gather kernel family is fixed here, with the postings: the partial rows, the rounds and seg_lo are sized for it,
+    //  so a later change of the option must not change the kernel that walks them)
     c->gather_rows = ctx->gather_rows;
-    using Round = pylda_corpus::Round;
-    std::vector<CutPiece> pieces;
-    int cut_threads = 1;
     // the persistent sweep (sstats_sweep.h) instead of partial rows: its geometry must be resident, one workgroup per CU
-    bool want_sweep = false;
-    if (NB > 1 && nnz > 0 && ctx->gather_sweep && (ctx->ldk == 128 || ctx->ldk == 256) && ctx->gather_rows == 2) {
-        const SweepGeom g = sweep_geom_for(ctx, V);
-        c->sweep_terms = g.T;
-        c->sweep_wpb = g.WPB;
-        c->sweep_passes = g.passes;
-        // (mode 1: only where the (term, block) partial rows - about V x NB of them - would not fit their budget)
-        const double budget = round_budget;
-        const double rows_bytes = ((double)std::min<int64_t>((int64_t)V * NB, nnz) + (double)nnz / kSegment) * ctx->ldk * sizeof(double);
-        int per_cu = 0;
+    const SweepGeom sg = sweep_geometry(g);
+    c->sweep_terms = sg.T;
+    c->sweep_wpb = sg.WPB;
+    c->sweep_passes = sg.passes;
+    int per_cu = 0;
+    if (NB > 1 && (ctx->ldk == 128 || ctx->ldk == 256)) {
 #define SWEEP_OCC(NCH, T, WPB, P) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sstats_sweep_kernel<NCH, T, WPB, P>, kWave * WPB, 0)
         PYLDA_SWEEP_DISPATCH(ctx, c, SWEEP_OCC);
 #undef SWEEP_OCC
-        want_sweep = per_cu >= 1 && (ctx->gather_sweep == 2 || rows_bytes > budget);
     }
-    const int64_t segment_cap = want_sweep ? kSweepSegment : kSegment;
+    const bool want_sweep = sweep_wanted(g, NB, per_cu >= 1);
+
+    SegmentCut cut;
     if (NB > 1) {
-        // the documents of the postings come back through a page-locked buffer (0.8 GB at cfg 4: 16 ms instead of the
-        // pageable copy's 0.3 s) and the cut runs on all host threads, term ranges side by side (it took 0.4 s)
-        int32_t* post_doc = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void**>(&post_doc), (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t), hipHostMallocDefault) != hipSuccess)
-            return fail(ctx, PYLDA_ERR_OOM, "postings: page-locked staging buffer");
-        struct Pinned { int32_t* p; ~Pinned() { (void)hipHostFree(p); } } pinned{post_doc};
-        timer.lap("page-locked staging buffer");
-        if (nnz > 0 && hipMemcpy(post_doc, c->d_post_doc, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(ctx, PYLDA_ERR_HIP, "postings: D2H copy failed");
+        PinnedDocs docs;
+        rc = docs.fetch(ctx, c);
+        if (rc != PYLDA_OK) return rc;
         timer.lap("documents of the postings D2H");
-        const int64_t per_block = (c->D + NB - 1) / NB;
         // (a forced round budget - tests - cuts at least 8 pieces so that small corpora get several rounds as well)
         const int nthreads = (int)std::max<int64_t>(ctx->gather_round_mb > 0 ? 8 : 1,
                                                     std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 32, nnz / 2000000 + 1}));
-        using Piece = CutPiece;
-        cut_threads = nthreads;
-        pieces.assign((size_t)nthreads, Piece());
-        run_on_threads(nthreads, [&](int t) {
-            // thread t: the terms whose postings start in its 1 / nthreads share of the posting range
-            Piece& out = pieces[(size_t)t];
-            out.per_block.assign((size_t)NB, 0);
-            const int64_t from = nnz * t / nthreads, to = nnz * (t + 1) / nthreads;
-            const int v0 = (int)(std::lower_bound(col_ptr.begin(), col_ptr.end() - 1, from) - col_ptr.begin());
-            const int v1 = t + 1 == nthreads ? V : (int)(std::lower_bound(col_ptr.begin(), col_ptr.end() - 1, to) - col_ptr.begin());
-            out.v0 = v0;
-            out.per_word.reserve((size_t)std::max(0, v1 - v0));
-            for (int v = v0; v < v1; ++v) {
-                int64_t b = col_ptr[(size_t)v], n = 0;
-                while (b < col_ptr[(size_t)v + 1]) {
-                    const int32_t blk = (int32_t)(post_doc[(size_t)b] / per_block);
-                    const int64_t block_end = ((int64_t)blk + 1) * per_block;       // first document of the next block
-                    const int64_t cap = std::min<int64_t>(col_ptr[(size_t)v + 1], b + segment_cap);
-                    int64_t e = b + 1;
-                    while (e < cap && post_doc[(size_t)e] < block_end) ++e;
-                    out.begin.push_back(b);
-                    out.end.push_back(e);
-                    out.block.push_back(blk);
-                    out.per_block[(size_t)blk] += 1;
-                    b = e;
-                    ++n;
-                }
-                out.per_word.push_back(n);
-            }
-        });
-        int64_t total = 0;
-        int covered = 0;
-        for (Piece& piece : pieces) {               // the pieces cover the terms in order
-            if (piece.v0 != covered) return fail(ctx, PYLDA_ERR_STATE, "postings: the segment cut lost terms at %d", covered);
-            piece.base = total;
-            total += (int64_t)piece.begin.size();
-            covered += (int)piece.per_word.size();
-        }
-        if (covered != V) return fail(ctx, PYLDA_ERR_STATE, "postings: the segment cut covered %d of %d terms", covered, V);
-        seg_begin.resize((size_t)total);
-        seg_end.resize((size_t)total);
-        run_on_threads(nthreads, [&](int t) {
-            const Piece& piece = pieces[(size_t)t];
-            std::copy(piece.begin.begin(), piece.begin.end(), seg_begin.begin() + piece.base);
-            std::copy(piece.end.begin(), piece.end.end(), seg_end.begin() + piece.base);
-            int64_t at = piece.base;
-            for (size_t i = 0; i < piece.per_word.size(); ++i) {
-                at += piece.per_word[i];
-                word_seg_ptr[(size_t)piece.v0 + i + 1] = at;
-            }
-        });
+        const char* err = cut_segments_blocked(col_ptr.data(), docs.p, V, c->D, nnz, NB, want_sweep ? kSweepSegment : kSegment, nthreads, &cut);
+        if (err) return fail(ctx, PYLDA_ERR_STATE, "postings: %s", err);
         timer.lap("segment cut");
     } else {
-        for (int v = 0; v < V; ++v) {
-            for (int64_t b = col_ptr[v]; b < col_ptr[v + 1]; b += kSegment) {
-                seg_begin.push_back(b);
-                seg_end.push_back(std::min<int64_t>(b + kSegment, col_ptr[v + 1]));
-            }
-            word_seg_ptr[v + 1] = (int64_t)seg_begin.size();
-        }
+        cut_segments_plain(col_ptr.data(), V, &cut);
     }
-    c->nseg = (int64_t)seg_begin.size();
+    c->nseg = (int64_t)cut.seg_begin.size();
     c->gather_blocks = NB;
     c->rounds.clear();
     c->sweep = false;
     if (want_sweep && c->nseg > 0) {
-        // the persistent sweep: every wavefront owns a few terms, all workgroups walk the document blocks together
-        const int T = c->sweep_terms;
-        const int64_t nwaves = (int64_t)ctx->num_cu * c->sweep_wpb;
-        const int passes = c->sweep_passes;
-        // terms by posting count, largest first, dealt boustrophedon over the wavefronts: equal work per block
-        std::vector<int32_t> by_df((size_t)V);
-        std::iota(by_df.begin(), by_df.end(), 0);
-        std::stable_sort(by_df.begin(), by_df.end(), [&](int32_t a, int32_t b) {
-            return col_ptr[(size_t)a + 1] - col_ptr[(size_t)a] > col_ptr[(size_t)b + 1] - col_ptr[(size_t)b];
-        });
-        std::vector<int32_t> term_of((size_t)passes * nwaves * T, -1);
-        for (int64_t j = 0; j < V; ++j) {
-            const int64_t row = j / nwaves, col = (row & 1) ? nwaves - 1 - j % nwaves : j % nwaves;
-            term_of[(size_t)(((row / T) * nwaves + col) * T + row % T)] = by_df[(size_t)j];
-        }
-        std::vector<int32_t> seg_block_all((size_t)c->nseg);
-        run_on_threads(cut_threads, [&](int t) {
-            std::copy(pieces[(size_t)t].block.begin(), pieces[(size_t)t].block.end(), seg_block_all.begin() + pieces[(size_t)t].base);
-        });
-        A(dev_alloc(ctx, &c->d_seg_block, (size_t)c->nseg));
-        A(dev_alloc(ctx, &c->d_term_of, term_of.size()));
-        A(dev_alloc(ctx, &c->d_rendezvous, (size_t)kSweepCounters * 32));      // one counter per XCD, a cache line apart
-        dev_free(c->d_entropy_partial);
-        A(dev_alloc(ctx, &c->d_entropy_partial, (size_t)passes * nwaves));
-        if (rc != PYLDA_OK) return rc;
-        if (hipMemcpy(c->d_seg_block, seg_block_all.data(), seg_block_all.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(c->d_term_of, term_of.data(), term_of.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
-            return fail(ctx, PYLDA_ERR_HIP, "postings: H2D copy failed");
-        c->sweep = true;
-        c->ent_blocks = (int64_t)passes * nwaves;
-        c->partial_rows = 0;
-    }
-    const int64_t ldk_rows = ctx->ldk;
-    auto blocks_of = [&](int n_words) { return ((int64_t)n_words * ldk_rows + 255) / 256; };
-    if (c->sweep) {
-        // (no partial rows, no execution order)
+        rc = install_sweep(ctx, c, cut, col_ptr);
     } else if (NB > 1 && c->nseg > 0) {
-        // rounds: groups of consecutive pieces (contiguous term ranges), each within the budget of partial rows
-        const double row_bytes = (double)ctx->ldk * sizeof(double);
-        const double budget = round_budget;
-        const int64_t max_rows = std::max<int64_t>(1, (int64_t)(budget / row_bytes));
-        std::vector<std::pair<size_t, size_t>> groups;        // [first piece, last piece + 1)
-        for (size_t t = 0; t < pieces.size();) {
-            size_t u = t + 1;
-            int64_t rows = (int64_t)pieces[t].begin.size();
-            while (u < pieces.size() && rows + (int64_t)pieces[u].begin.size() <= max_rows) rows += (int64_t)pieces[u++].begin.size();
-            groups.emplace_back(t, u);
-            t = u;
-        }
-        // XCD x works through the segments of blocks x, x + 8, ... block after block; workgroup g (4 wavefronts)
-        // takes slots 4 * (g / 8) .. + 3 of the list of XCD g % 8.  A block's segments keep their order (term by term);
-        // a block starts on a multiple of 4 slots (a workgroup never mixes two blocks' rows).  One such order per round.
-        constexpr int kXcd = 8;
-        std::vector<int64_t> round_slot0(groups.size() + 1, 0);
-        std::vector<std::vector<int64_t>> cursor(pieces.size(), std::vector<int64_t>((size_t)NB, 0));
-        for (size_t g = 0; g < groups.size(); ++g) {
-            int64_t list_len[kXcd] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int b = 0; b < NB; ++b) {
-                int64_t at = list_len[b % kXcd];
-                for (size_t t = groups[g].first; t < groups[g].second; ++t) {
-                    cursor[t][(size_t)b] = at;                // where piece t's segments of block b go: behind the earlier pieces'
-                    at += pieces[t].per_block[(size_t)b];
-                }
-                list_len[b % kXcd] = (at + 3) / 4 * 4;
-            }
-            const int64_t longest = *std::max_element(list_len, list_len + kXcd);
-            round_slot0[g + 1] = round_slot0[g] + longest * kXcd;
-            Round r;
-            const CutPiece& head = pieces[groups[g].first];
-            const CutPiece& tail = pieces[groups[g].second - 1];
-            r.seg_lo = head.base;
-            r.seg_hi = tail.base + (int64_t)tail.begin.size();
-            r.w_first = head.v0;
-            r.n_words = tail.v0 + (int)tail.per_word.size() - head.v0;
-            r.slot_lo = round_slot0[g];
-            r.slot_count = longest * kXcd;
-            r.ent_first = c->rounds.empty() ? 0 : c->rounds.back().ent_first + c->rounds.back().ent_blocks;
-            r.ent_blocks = blocks_of(r.n_words);
-            c->rounds.push_back(r);
-        }
-        std::vector<int32_t> order((size_t)round_slot0.back(), -1);
-        std::vector<size_t> group_of(pieces.size(), 0);
-        for (size_t g = 0; g < groups.size(); ++g)
-            for (size_t t = groups[g].first; t < groups[g].second; ++t) group_of[t] = g;
-        run_on_threads(cut_threads, [&](int t) {
-            const CutPiece& piece = pieces[(size_t)t];
-            std::vector<int64_t>& cur = cursor[(size_t)t];
-            const int64_t slot0 = round_slot0[group_of[(size_t)t]];
-            for (size_t k = 0; k < piece.block.size(); ++k) {
-                const int32_t b = piece.block[k];
-                const int64_t i = cur[(size_t)b]++;
-                order[(size_t)(slot0 + ((i / 4) * kXcd + b % kXcd) * 4 + i % 4)] = (int32_t)(piece.base + (int64_t)k);
-            }
-        });
-        c->exec_slots = (int64_t)order.size();
-        A(dev_alloc(ctx, &c->d_exec_order, order.size()));
-        if (rc != PYLDA_OK) return rc;
-        if (hipMemcpy(c->d_exec_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
-            return fail(ctx, PYLDA_ERR_HIP, "postings: H2D copy failed");
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        const int64_t max_rows = (int64_t)(round_budget(g, free_b) / ((double)ctx->ldk * sizeof(double)));
+        rc = install_rounds(ctx, c, plan_rounds(cut, NB, max_rows, ctx->ldk));
     } else {
-        c->rounds.push_back(Round{0, c->nseg, 0, V, 0, c->nseg, 0, blocks_of(V)});
-    }
-    if (!c->sweep) {
-        c->partial_rows = 0;
-        for (const Round& r : c->rounds) c->partial_rows = std::max(c->partial_rows, r.seg_hi - r.seg_lo);
-        c->ent_blocks = c->rounds.back().ent_first + c->rounds.back().ent_blocks;
-    }
-    timer.lap("XCD execution order");
-    A(dev_alloc(ctx, &c->d_seg_begin, (size_t)c->nseg));
-    A(dev_alloc(ctx, &c->d_seg_end, (size_t)c->nseg));
-    A(dev_alloc(ctx, &c->d_word_seg_ptr, (size_t)V + 1));
-    timer.lap("segment array allocations");
-    if (!c->sweep) {
-        A(dev_alloc(ctx, &c->d_partial, (size_t)c->partial_rows * ctx->ldk));
-        dev_free(c->d_entropy_partial);
-        A(dev_alloc(ctx, &c->d_entropy_partial, (size_t)c->ent_blocks));
+        rc = install_rounds(ctx, c, single_round(c->nseg, V, ctx->ldk));
     }
     if (rc != PYLDA_OK) return rc;
-    timer.lap("partial rows allocation");
-    auto H2D = [&](void* dst, const void* src, size_t bytes) {
-        if (rc == PYLDA_OK && bytes && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
-            rc = fail(ctx, PYLDA_ERR_HIP, "postings: H2D copy failed");
-    };
-    H2D(c->d_seg_begin, seg_begin.data(), (size_t)c->nseg * sizeof(int64_t));
-    H2D(c->d_seg_end, seg_end.data(), (size_t)c->nseg * sizeof(int64_t));
-    H2D(c->d_word_seg_ptr, word_seg_ptr.data(), ((size_t)V + 1) * sizeof(int64_t));
+    timer.lap("execution order, partial rows");
+    rc = upload(ctx, &c->d_seg_begin, cut.seg_begin);
+    if (rc == PYLDA_OK) rc = upload(ctx, &c->d_seg_end, cut.seg_end);
+    if (rc == PYLDA_OK) rc = upload(ctx, &c->d_word_seg_ptr, cut.word_seg_ptr);
     if (rc != PYLDA_OK) return rc;
     timer.lap("segment arrays H2D");
     c->have_postings = true;

@@ -64,3 +64,69 @@ def test_two_rank_gloo_allreduce_matches_single_process(tmp_path):
         assert int(r["D"]) == 400
         assert np.max(np.abs(r["alpha_ss"] - alpha_ss)) < 1e-9
     assert np.array_equal(r0["sstats"], r1["sstats"])      # every rank holds the identical reduced buffer
+
+
+def _gather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pylda_amd import cli
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(rank)
+    rows = [5, 0, 3][rank]                                   # (a rank without documents sends nothing)
+    gamma = rng.random((rows, 4)) + rank
+    whole = cli._gather_rows(gamma, rank, world)
+    ids = cli._gather_rows(np.arange(rows * 2, dtype=np.int32) + 100 * rank, rank, world)
+    np.save(os.path.join(out_dir, "gamma%d.npy" % rank), gamma)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "whole.npy"), whole)
+        np.save(os.path.join(out_dir, "ids.npy"), ids)
+    else:
+        assert whole is None and ids is None
+    dist.destroy_process_group()
+
+
+def test_rank_zero_gathers_rows_without_pickling(tmp_path):
+    """launch_train --gpus N: gamma and the corpus shards reach rank 0 as tensor receives into slices of ONE
+    pre-allocated array (gather_object pickled 2 GB at cfg 4), in rank order, empty shards included."""
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / ("gamma%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(np.load(tmp_path / "whole.npy"), np.concatenate(parts, axis=0))
+    assert np.array_equal(np.load(tmp_path / "ids.npy"),
+                          np.concatenate([np.arange(10, dtype=np.int32), np.arange(6, dtype=np.int32) + 200]))
+
+
+def test_line_ranges_balance_bytes_and_cover():
+    sys.path.insert(0, ROOT)
+    from pylda_amd import cli
+    rng = np.random.default_rng(0)
+    docs = ["w" * int(n) for n in rng.integers(0, 400, 1000)]
+    for world in (1, 2, 3, 8):
+        b = cli._line_ranges(docs, world)
+        assert b[0] == 0 and b[-1] == 1000 and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
+        weights = [sum(len(d) + 1 for d in docs[lo:hi]) for lo, hi in zip(b, b[1:])]
+        assert max(weights) - min(weights) <= 2 * 401                         # within a line or two of each other
+    assert cli._line_ranges([], 4) == [0, 0, 0, 0, 0]
+    assert cli._line_ranges(["a", "b"], 8)[-1] == 2                           # more ranks than lines: empty shards
+
+
+def test_launch_train_refuses_a_world_it_was_not_asked_for(monkeypatch):
+    """`--gpus 4` under a launcher with WORLD_SIZE=1 ran as one rank without a word; WORLD_SIZE without RANK
+    raised a KeyError."""
+    sys.path.insert(0, ROOT)
+    from pylda_amd import cli
+    opt = cli._parse(cli.TRAIN_FLAGS, ["--gpus=4"], "launch_train")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit, match="does not match"):
+        cli._join_ranks(opt)
+    opt = cli._parse(cli.TRAIN_FLAGS, ["--gpus=2"], "launch_train")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit, match="RANK is not"):
+        cli._join_ranks(opt)
+    monkeypatch.delenv("WORLD_SIZE")
+    opt = cli._parse(cli.TRAIN_FLAGS, [], "launch_train")
+    assert cli._join_ranks(opt) == (0, 1, 0, None)
