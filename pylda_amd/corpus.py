@@ -191,64 +191,3 @@ def corpus_checksum(doc_ptr, term_id, term_ct):
     """(documents, nnz, sum of term ids, sum of counts): identifies a generated corpus in bench records."""
     return [int(len(doc_ptr) - 1), int(doc_ptr[-1]), int(np.asarray(term_id, dtype=np.int64).sum()),
             int(np.asarray(term_ct, dtype=np.int64).sum())]
-
-
-def synthetic_lda_corpus_torch(num_docs, vocab_size, true_topics=128, mean_len=200, seed=1234,
-                               topic_concentration=0.01, doc_concentration=0.1, device="cpu",
-                               chunk=25000, first_chunk=0, shard_chunks=None):
-    """The same generative process as synthetic_lda_corpus, drawn with torch on
-    `device` (on the GPU a 100k-document corpus takes about a second; host RAM
-    is never asked for the token stream).  Streams differ from the numpy
-    generator's: a corpus is identified by (generator, seed, device type).
-
-    Chunks of `chunk` documents are seeded independently (seed, chunk index),
-    so rank r of a sharded run can draw chunks [first_chunk, first_chunk +
-    shard_chunks) of the global corpus without the rest.
-    Returns numpy CSR (doc_ptr int64, term_id int32, term_ct int32)."""
-    import torch
-    dev = torch.device(device)
-    f64 = torch.float64
-
-    def gen(s):
-        g = torch.Generator(device=dev)
-        g.manual_seed(int(s))
-        return g
-
-    def dirichlet_rows(g, conc, rows, cols):
-        x = torch._standard_gamma(torch.full((rows, cols), conc, dtype=f64, device=dev), generator=g)
-        return x / x.sum(dim=1, keepdim=True)
-
-    g0 = gen(seed * 1000003 + 1)
-    beta = dirichlet_rows(g0, topic_concentration, true_topics, vocab_size)
-    word_cdf = torch.cumsum(beta, dim=1)
-    word_cdf = word_cdf / word_cdf[:, -1:]
-    word_cdf = (word_cdf + torch.arange(true_topics, device=dev, dtype=f64)[:, None]).reshape(-1)
-    del beta
-    n_chunks = (num_docs + chunk - 1) // chunk
-    last_chunk = n_chunks if shard_chunks is None else min(n_chunks, first_chunk + shard_chunks)
-    ptr_parts, id_parts, ct_parts = [np.zeros(1, np.int64)], [], []
-    base = 0
-    for ci in range(first_chunk, last_chunk):
-        n = min(chunk, num_docs - ci * chunk)
-        g = gen(seed * 1000003 + 2 + ci)
-        theta = dirichlet_rows(g, doc_concentration, n, true_topics)
-        lengths = torch.poisson(torch.full((n,), float(mean_len), dtype=f64, device=dev),
-                                generator=g).clamp_(min=1).to(torch.int64)
-        doc = torch.repeat_interleave(torch.arange(n, device=dev), lengths)
-        topic_cdf = torch.cumsum(theta, dim=1)
-        topic_cdf = topic_cdf / topic_cdf[:, -1:]
-        topic_cdf = (topic_cdf + torch.arange(n, device=dev, dtype=f64)[:, None]).reshape(-1)
-        u = torch.rand(doc.numel(), dtype=f64, device=dev, generator=g)
-        z = torch.searchsorted(topic_cdf, u + doc.to(f64), right=True) - doc * true_topics
-        z.clamp_(0, true_topics - 1)
-        u = torch.rand(doc.numel(), dtype=f64, device=dev, generator=g)
-        w = torch.searchsorted(word_cdf, u + z.to(f64), right=True) - z * vocab_size
-        w.clamp_(0, vocab_size - 1)
-        uniq, counts = torch.unique(doc * vocab_size + w, return_counts=True)
-        per_doc = torch.bincount(uniq // vocab_size, minlength=n)
-        id_parts.append((uniq % vocab_size).to(torch.int32).cpu().numpy())
-        ct_parts.append(counts.to(torch.int32).cpu().numpy())
-        ptr_parts.append(base + torch.cumsum(per_doc, 0).cpu().numpy())
-        base += int(per_doc.sum())
-    return (np.concatenate(ptr_parts).astype(np.int64), np.concatenate(id_parts),
-            np.concatenate(ct_parts))

@@ -40,17 +40,6 @@
 
 namespace pylda {
 
-// Development builds only (tools/phase_stamps_quad.py compiles a copy with -DPYLDA_QUAD_STAMPS=1): s_memtime stamps
-// around the phases of the inner loop; the instrumentation itself lives in tools/quad_stamps.h.
-#if defined(PYLDA_QUAD_STAMPS) && PYLDA_QUAD_STAMPS
-#include "../../tools/quad_stamps.h"
-#else
-#define PYLDA_QUAD_STAMPS 0
-#define QUAD_STAMP(j) do { } while (0)
-#define QUAD_STAMPS_BEGIN() do { } while (0)
-#define QUAD_STAMPS_DUMP() do { } while (0)
-#endif
-
 template <int TL, int RWL, int TWL>
 struct QuadLds {
     static constexpr int W = TL / 4;                                               // wavefronts per document
@@ -133,7 +122,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     double* gpv = reinterpret_cast<double*>(smem + L::gpv);
     double* cntv = reinterpret_cast<double*>(smem + L::cnt);    // (as doubles: no int -> fp64 conversion per iteration)
 
-    QUAD_STAMPS_BEGIN();
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -306,7 +294,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     LdsRow sbuf;
     auto request_srow = [&](int s) { table_row_request<TL * 16>(sbuf, p.expElog, srow[s]); };
     if constexpr (SWL > 0) request_srow(0);                               // (slot 0 is never empty: N > 16 * WPR)
-    QUAD_STAMP(8);                                                        // prologue: gather, first t
     for (;;) {                                                            // :174
         const int buf = it & 1;
 
@@ -365,7 +352,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         }
 #pragma unroll
         for (int i = 0; i < C0; ++i) myred[i * RS + cw] = PRE ? lane_group_sum<2>(a[i]) : a[i];
-        QUAD_STAMP(0);                                                    // t wait + pass A over slots 0-7 (+ rows 0, 1) + writes
         if (moved <= thresh || left <= 0) {                               // :189 (mean <= tol), :174
             if constexpr (TWL > 2) lds_row_wait(rowbuf);                  // no read may land after the loop (row 2 is in flight)
             if constexpr (SWL > 1) table_row_wait(sbuf);
@@ -386,7 +372,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             stream_partial(StaticIndex<3>());                             // (the last streamed row likewise)
             double s0 = finish_sum(h0);
             asm volatile("" : "+v"(s0));                                  // h0 is dead from here on
-            QUAD_STAMP(1);                                                // slots 8.., rows 2, 3, first transpose landed and summed
             wave_lds_exchange();                                          // the writes below stay behind the reads above
             if constexpr (PRE && R1 > 0) asm volatile("s_nop 1" : "+v"(a1[R1 - 1]));       // (as above: dot8's last add)
             if constexpr (PRE && TWL > 0) asm volatile("s_nop 1" : "+v"(pr[TWL - 1]));
@@ -414,7 +399,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         }
 
         dpp_source_ready(r0);
-        QUAD_STAMP(2);                                                    // second transpose, first reciprocal chain
 
         // B. q[k] over this lane's words (registers and LDS rows interleaved), then over the word groups
         double q[KRL];
@@ -495,7 +479,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
                 mysp[2 * c + (j & 1) + 2 * TL * (j >> 1)] = v;
             }
         }
-        QUAD_STAMP(3);                                                    // pass B + swaps + partials written
         // both coefficient tables of exp_digamma_minus_levels, requested ahead of the barrier: the scalar-cache
         // round trips (150-200 ticks each when taken inside the phase) ride on the barrier wait
         ExpDigammaLevelsA coef_a;
@@ -505,7 +488,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             coef_b.load();
         }
         __syncthreads();
-        QUAD_STAMP(4);                                                    // barrier 1
 
         // C. gamma update by the topic threads
         if (topic_thread) {
@@ -514,7 +496,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             for (int w = 0; w < W; ++w) part_sum[w] = red[(size_t)w * (L::red_wave / 8) + ktid];
             const double t_mine = tt[buf * KT + ktid], alpha_k = alf[ktid];
             keep_together(part_sum);
-            QUAD_STAMP(5);                                                // partial sums arrived
             double s0 = part_sum[0] + part_sum[1], s1 = part_sum[2] + part_sum[3];
             if constexpr (W == 8) {
                 s0 += part_sum[4] + part_sum[5];
@@ -525,17 +506,13 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             gpv[ktid] = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
-            QUAD_STAMP(11);                                               // gamma update, change into the fixed-point sum
             const double t_next = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
-            QUAD_STAMP(12);                                               // exp(psi(gamma) - psi(sum))
             tt[(buf ^ 1) * KT + ktid] = topic_live ? t_next : 0.0;
             if (ktid == 0) store_u64_hi(&chg[buf ^ 1], 0u);
         }
         ++it;
         --left;
-        QUAD_STAMP(6);                                                    // gamma phase
         __syncthreads();
-        QUAD_STAMP(7);                                                    // barrier 2
         moved = (long long)chg[buf];
 #pragma unroll
         for (int jj = 0; jj < KRL / 2; ++jj) {
@@ -545,7 +522,6 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         }
     }
     const int last = (it - 1) & 1;          // tt[last] holds t of the last executed iteration
-    QUAD_STAMP(9);                                                        // the half iteration behind the last update
 
     bad = __syncthreads_or(bad);
     if (bad) {
@@ -559,7 +535,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
 
     // ---- training fast path: the document terms are left to doc_terms_kernel (doc_terms.h), which recomputes
     //      them from gamma, t and r at full occupancy instead of on this workgroup's handful of wavefronts ----
-    if (!p.heldout && !p.want_doc_ll && !PYLDA_QUAD_STAMPS) {
+    if (!p.heldout && !p.want_doc_ll) {
         if (live0 && part == 0) p.rfinal[lo + word0] = r0;
         if (live1 && part == 0) p.rfinal[lo + word1] = r1;
         if (topic_thread) {
@@ -622,12 +598,11 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         if (p.heldout) lse_term = p.topic_lse[ktid] * mass;
         lgam = lgamma_pos(gam);
         gsum = gam;
-        if (!PYLDA_QUAD_STAMPS) p.gamma[(size_t)doc * K + ktid] = gam;
+        p.gamma[(size_t)doc * K + ktid] = gam;
         if (!p.heldout) p.tfinal[(size_t)doc * ldk + ktid] = t_last;
     } else if (topic_thread && !p.heldout) {
         p.tfinal[(size_t)doc * ldk + ktid] = 0.0;
     }
-    QUAD_STAMPS_DUMP();                                                   // (development builds: epilogue stamp, per-wavefront sums over the gamma row)
     term1 = wave_sum(term1);
     term2 = wave_sum(term2);
     lse_term = wave_sum(lse_term);

@@ -88,11 +88,7 @@ def test_synthetic_generators_small():
         assert np.all(np.diff(w) > 0)
     a = C.synthetic_lda_shard(300, 200, 100, 200, true_topics=5, mean_len=30, seed=3, chunk=100)
     assert np.array_equal(a[1], ids[ptr[100]:ptr[200]])                 # shard == slice of the whole
-    p2, i2, c2 = C.synthetic_lda_corpus_torch(300, 200, 5, 30, seed=3, chunk=100)
-    assert len(p2) == 301 and p2[-1] == i2.size and c2.min() >= 1 and i2.max() < 200
-    p3, i3, c3 = C.synthetic_lda_corpus_torch(300, 200, 5, 30, seed=3, chunk=100, first_chunk=1, shard_chunks=1)
-    assert np.array_equal(i3, i2[p2[100]:p2[200]]) and np.array_equal(c3, c2[p2[100]:p2[200]])
-    assert abs(c2.sum() / 300.0 - 30) < 3                               # mean length as requested
+    assert abs(cts.sum() / 300.0 - 30) < 3                                # mean length as requested
 
 
 def reference_rules_parse(lines, type_to_index):
