@@ -75,7 +75,8 @@ struct pylda_ctx {
     double beta_sum = 0.0, beta_lgamma_sum = 0.0;
 
     std::vector<double> h_alpha;
-    // pinned host staging (one allocation): two alpha slots (K each) + the outer-iteration read-back (2K + 8)
+    // pinned host staging (one allocation, 5K + 8 doubles): two alpha slots (K each), the outer-iteration read-back (3K + 4),
+    // the E-step's scalars (4)
     double* h_pin = nullptr;
     hipEvent_t alpha_event[2] = {nullptr, nullptr};
     bool alpha_event_used[2] = {false, false};
