@@ -263,10 +263,10 @@ int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
  *   "force_logspace" 0|1  run every document through the log-space
  *                         safety-net kernel (the reference's formulation);
  *   "force_variant"  -1 (automatic) or a kernel variant index: 0..2 generic LDS 64/256/512
- *                    threads, 3 generic global, 4 slab, 6 quilt, 7 streaming, 8 hybrid, 9 wide
- *                    tiered, 10 quad, 11 fused streaming, 12 generic with the per-term scalars in global memory
- *                    (documents of any length), 13 fused streaming for 512 < K <= 1024 (5 was round 1's column
- *                    kernel, removed);
+ *                    threads, 3 generic global, 4 slab, 6 quilt, 9 group-fused streaming (more than 256 terms at
+ *                    table stride 64 / 128 / 256), 10 quad, 11 fused streaming, 12 generic with the per-term scalars
+ *                    in global memory (documents of any length), 13 fused streaming for 512 < K <= 1024 (5, 7, 8 were
+ *                    the column, two-pass streaming and hybrid kernels of rounds 1-2, removed);
  *                    a variant that cannot take a document falls back to the automatic choice;
  *   "gather_rows"    statistics gather (variational_bayes.py:207): 0 64-topic chunks, 1 whole rows,
  *                    2 (default) whole rows with the postings fetched in bulk (table stride 128 / 256);
