@@ -1,8 +1,8 @@
 // Fused streaming E-step kernel for 256 < K <= 512 (table stride 384 or 512 = 128 * NP; cfg 5:
 // nips.88-05 at K = 500, N_d ~ 230, tile 230 x 4 KiB = 920 KB - more than a CU holds).
 //
-// The two-pass streaming kernel (estep_qstream.h) re-reads the whole tile from L2 / Infinity Cache
-// twice per inner iteration; at K = 500 every CU streams 1.8 MB per document-iteration and the chip is
+// Round 2's two-pass streaming kernel (retired) re-read the whole tile from L2 / Infinity Cache
+// twice per inner iteration; at K = 500 every CU streamed 1.8 MB per document-iteration and the chip was
 // bound by the fabric (6.8 TB/s in aggregate, 95 % of wave-cycles waiting:
 // profiles/r02_nips_k500_qstream_rocprof_summary.txt).  Two observations cut that traffic ~3x:
 //

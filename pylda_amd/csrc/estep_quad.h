@@ -12,8 +12,8 @@
 // on a different SIMD, at <= 256 VGPRs, so two documents are co-resident per CU and every SIMD
 // alternates between them (measured: 205 ns per document with two per CU, 338 ns with one).
 // At K = 256 the tile (N_d x 2 KiB = 400 KiB) leaves room for one document per CU; the same body
-// runs with eight wavefronts, and - unlike the tiered kernel of estep_qwide.h - keeps EVERY word
-// of a document of up to 208 terms on chip: nothing is re-read from L2 inside the loop.
+// runs with eight wavefronts, and - unlike the tiered kernels of rounds 1-2 - keeps EVERY word
+// of a document of up to 224 terms on chip: nothing is re-read from L2 inside the loop.
 //
 // Layout.  lane = TL*g + c: word group g, topic lane c; a lane holds 8 values of a table row:
 // topics 2c + 2*TL*jj + {0,1}, jj < 4 (16-byte pieces, TL*16 bytes apart).  A document has 16 word

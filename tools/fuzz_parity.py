@@ -18,7 +18,7 @@ def sweep(budget=60.0, seed=0, verbose=True):
                             513, 640, 700, 768, 800, 1000, 1024, 1100]))
         V = int(rng.integers(max(20, K // 4), 5000))
         D = int(rng.integers(1, 40))
-        mean_len = float(rng.choice([3, 20, 80, 150, 200, 215, 240, 300, 500]))
+        mean_len = float(rng.choice([3, 20, 80, 150, 200, 215, 232, 240, 250, 300, 500, 800]))
         ptr, ids, cts = [0], [], []
         for _ in range(D):
             n = int(min(V, max(1, rng.poisson(mean_len))))
