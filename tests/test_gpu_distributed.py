@@ -425,6 +425,36 @@ def test_launch_train_over_two_ranks_writes_the_same_files(ap_train, tmp_path):
     assert np.isfinite(words_ll) and gamma.shape == (1, 5)
 
 
+def test_launch_train_with_more_ranks_than_documents(ap_train, tmp_path):
+    """Three ranks, two documents (and an empty line between them): every rank parses ITS line range only, so one rank
+    holds no document at all - it still joins both all-reduces of every iteration, and rank 0 gathers gamma and the
+    corpus from shards of 1, 0 and 1 documents."""
+    import pickle
+    import subprocess
+    import sys
+    corpus_dir = _write_mini_press(ap_train, tmp_path, n_docs=2)
+    lines = (corpus_dir / "train.dat").read_text().splitlines()
+    (corpus_dir / "train.dat").write_text(lines[0] + "\n\n" + lines[1] + "\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PYLDA_SEED"] = "5"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    runs = {}
+    for gpus in (1, 3):
+        out_dir = tmp_path / ("out%d" % gpus)
+        cmd = [sys.executable, "-m", "pylda_amd.launch_train", "--input_directory=%s/" % corpus_dir,
+               "--output_directory=%s" % out_dir, "--number_of_topics=4", "--training_iterations=3", "--snapshot_interval=3"]
+        if gpus > 1:
+            cmd += ["--gpus=%d" % gpus, "--share_gpu=1"]
+        done = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+        assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
+        runs[gpus] = next((out_dir / "mini-press").iterdir())
+    assert (runs[1] / "exp_gamma-3").read_bytes() == (runs[3] / "exp_gamma-3").read_bytes()
+    one, three = (pickle.load(open(runs[k] / "model-3", "rb")) for k in (1, 3))
+    assert three._number_of_documents == 2 and three._gamma.shape == (2, 4)
+    assert rel_err(three._eta, one._eta) < 1e-12 and rel_err(three._gamma, one._gamma) < 1e-10
+    assert np.array_equal(three._train_csr[0], one._train_csr[0]) and np.array_equal(three._train_csr[1], one._train_csr[1])
+
+
 def test_collectives_are_issued_under_the_context_stream(nccl_group, ap_train, monkeypatch):
     """What orders E-step -> all-reduce -> M-step on the device is that BOTH collectives of an outer iteration are
     issued while torch's current stream is the stream the library's kernels run on.  At world size 1 the reduction
