@@ -12,10 +12,15 @@ int enqueue_prepare(pylda_ctx* ctx, bool heldout)
     const int K = ctx->K, V = ctx->V;
     hipLaunchKernelGGL(eta_rowsum_psi_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_eta, K, V,
                        ctx->d_psi_rowsum);
-    hipLaunchKernelGGL(elog_transpose_kernel, dim3((V + 31) / 32, (K + 31) / 32), dim3(256), 0,
-                       ctx->stream, ctx->d_eta, ctx->d_psi_rowsum, K, V, ctx->ldk, ctx->d_elog);
-    hipLaunchKernelGGL(row_shift_exp_kernel, dim3((V + 3) / 4), dim3(256), 0, ctx->stream,
-                       ctx->d_elog, K, V, ctx->ldk, ctx->d_expElog, ctx->d_expElog_elog, ctx->d_shift);
+    if (K <= 64 && (int64_t)K * V <= (1 << 21)) {
+        hipLaunchKernelGGL(elog_rows_small_kernel, dim3((V + 3) / 4), dim3(256), 0, ctx->stream, ctx->d_eta, ctx->d_psi_rowsum,
+                           K, V, ctx->ldk, ctx->d_elog, ctx->d_expElog, ctx->d_expElog_elog, ctx->d_shift);
+    } else {
+        hipLaunchKernelGGL(elog_transpose_kernel, dim3((V + 31) / 32, (K + 31) / 32), dim3(256), 0,
+                           ctx->stream, ctx->d_eta, ctx->d_psi_rowsum, K, V, ctx->ldk, ctx->d_elog);
+        hipLaunchKernelGGL(row_shift_exp_kernel, dim3((V + 3) / 4), dim3(256), 0, ctx->stream,
+                           ctx->d_elog, K, V, ctx->ldk, ctx->d_expElog, ctx->d_expElog_elog, ctx->d_shift);
+    }
     if (heldout)
         hipLaunchKernelGGL(topic_lse_kernel, dim3(K), dim3(256), 0, ctx->stream, ctx->d_elog,
                            ctx->d_shift, K, V, ctx->ldk, ctx->d_topic_lse);
@@ -132,9 +137,9 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
     A(dev_alloc(ctx, &c->d_doc_wll, (size_t)D));
     A(dev_alloc(ctx, &c->d_iters, (size_t)D));
     A(dev_alloc(ctx, &c->d_status, (size_t)D));
-    A(dev_alloc(ctx, &c->d_flag_list, (size_t)D));
-    A(dev_alloc(ctx, &c->d_flag_count, (size_t)1));
     A(dev_alloc(ctx, &c->d_scalars, (size_t)4));
+    // (the count of flagged documents lives in the fourth scalar's bytes: ONE read-back of 32 bytes per E-step)
+    c->d_flag_count = c->d_scalars ? reinterpret_cast<int32_t*>(c->d_scalars + 3) : nullptr;
     A(dev_alloc(ctx, &c->d_entropy_partial, (size_t)(((int64_t)ctx->V * ctx->ldk + 255) / 256)));
     A(dev_alloc(ctx, &c->d_tfinal, (size_t)D * ctx->ldk));
     A(dev_alloc(ctx, &c->d_rfinal, (size_t)nnz));
@@ -169,7 +174,7 @@ void pylda_corpus_destroy(pylda_corpus* c)
     }
     dev_free(c->d_doc_ptr); dev_free(c->d_term_id); dev_free(c->d_term_ct); dev_free(c->d_order);
     dev_free(c->d_gamma); dev_free(c->d_doc_ll); dev_free(c->d_doc_wll); dev_free(c->d_iters);
-    dev_free(c->d_status); dev_free(c->d_flag_list); dev_free(c->d_flag_count); dev_free(c->d_scalars); dev_free(c->d_entropy_partial);
+    dev_free(c->d_status); c->d_flag_count = nullptr; dev_free(c->d_scalars); dev_free(c->d_entropy_partial);
     dev_free(c->d_tfinal); dev_free(c->d_rfinal); dev_free(c->d_term_scratch); dev_free(c->d_post_doc);
     if (c->d_post_pos) (void)hipFree(c->d_post_pos);
     c->d_post_pos = nullptr;
@@ -204,7 +209,6 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     int rc = enqueue_prepare(ctx, heldout != 0);                      // :152-155
     if (rc != PYLDA_OK) return rc;
     if (!heldout && (rc = build_postings(c)) != PYLDA_OK) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(c->d_flag_count, 0, sizeof(int32_t), ctx->stream));
 
     EstepParams p;
     p.K = K;
@@ -375,21 +379,22 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         close_bracket(ss_bracket, ctx->stream);
         if (rc != PYLDA_OK) return rc;
     }
-    // safety net: documents the linear-space kernels flagged are redone in log space
+    // safety net: documents the linear-space kernels flagged are redone in log space (the kernel finds them itself)
     if (c->D > 0) {
-        hipLaunchKernelGGL(flagged_collect_kernel, dim3((unsigned)((c->D + 255) / 256)), dim3(256), 0,
-                           ctx->stream, c->d_status, c->D, c->d_flag_list, c->d_flag_count);
         p.order = nullptr;
-        const unsigned grid = (unsigned)std::min<int64_t>(c->D, 4 * (int64_t)ctx->num_cu);
-        if (logspace_lds_bytes(K) > 64 * 1024)
+        const unsigned grid = (unsigned)std::min<int64_t>((c->D + 255) / 256, 4 * (int64_t)ctx->num_cu);
+        const size_t list_offset = (logspace_lds_bytes(K) + 15) & ~(size_t)15, lds = list_offset + 257 * sizeof(int32_t);
+        if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(estep_logspace_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)logspace_lds_bytes(K)));
-        hipLaunchKernelGGL(estep_logspace_kernel, dim3(grid), dim3(256), logspace_lds_bytes(K),
-                           ctx->stream, p, ctx->d_elog, ctx->d_sstats, c->d_flag_list, c->d_flag_count);
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(estep_logspace_kernel, dim3(grid), dim3(256), lds, ctx->stream, p, ctx->d_elog, ctx->d_sstats,
+                           c->d_status, c->D, list_offset);
     }
-    hipLaunchKernelGGL(vector_sum3_kernel, dim3(heldout ? 2 : 3), dim3(1024), 0, ctx->stream, SumJob{c->d_doc_ll, c->D, c->d_scalars},
+    // the corpus-level sums and the number of documents redone, into the four scalars pylda_estep_results reads back
+    hipLaunchKernelGGL(vector_sum3_kernel, dim3(4), dim3(1024), 0, ctx->stream, SumJob{c->d_doc_ll, c->D, c->d_scalars},
                        SumJob{c->d_doc_wll, c->D, c->d_scalars + 1},
-                       SumJob{c->d_entropy_partial, heldout ? 0 : c->ent_blocks, heldout ? nullptr : c->d_scalars + 2});
+                       SumJob{c->d_entropy_partial, heldout ? 0 : c->ent_blocks, heldout ? nullptr : c->d_scalars + 2},
+                       c->d_status, c->D, c->d_flag_count);
     HIP_TRY(ctx, hipGetLastError());
     c->estep_done = true;
     c->last_heldout = heldout;
@@ -409,8 +414,7 @@ int pylda_estep_results(pylda_ctx* ctx, pylda_corpus* c, double* document_log_li
     // waited for by the runtime, twice (associated-press: 35 % of the E-step's wall time was this read-back)
     double* sc = ctx->h_pin + (size_t)5 * ctx->K + 4;
     int32_t* nflag_pin = reinterpret_cast<int32_t*>(sc + 3);
-    HIP_TRY(ctx, hipMemcpyAsync(sc, c->d_scalars, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(nflag_pin, c->d_flag_count, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(sc, c->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t nflag = *nflag_pin;
     // training fast path: the log B entropy term comes once per corpus from the statistics

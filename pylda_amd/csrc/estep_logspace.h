@@ -116,29 +116,32 @@ __device__ inline void logspace_document(const EstepParams& p, const double* __r
     }
 }
 
-// Documents flagged (status == 1) by the fast kernels are appended to `list`
-// by flagged_collect_kernel; this kernel grid-strides over that list, so the
-// host never has to read the count back inside the hot path.
+// Documents flagged (status == 1) by the fast kernels are found by this kernel itself: the workgroups stride over the
+// status array in chunks of 256 documents, collect a chunk's flagged documents in LDS and redo them one after the other
+// (the whole workgroup works on a document).  Neither the host nor another kernel builds a list: with nothing flagged -
+// every E-step of every BASELINE configuration - the safety net costs ONE dispatch of a few loads per thread.
+//   smem: logspace_lds_bytes(K) bytes for a document, then 256 + 1 ints for the chunk's list.
 __global__ __launch_bounds__(256) void estep_logspace_kernel(EstepParams p,
                                                              const double* __restrict__ elog_wk,
                                                              double* __restrict__ sstats_extra,
-                                                             const int32_t* __restrict__ list,
-                                                             const int32_t* __restrict__ count)
+                                                             const int32_t* __restrict__ status, int64_t D,
+                                                             size_t list_offset)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n = *count;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        logspace_document(p, elog_wk, sstats_extra, list[i], smem);
+    int32_t* found = reinterpret_cast<int32_t*>(smem + list_offset);
+    int32_t* nfound = found + 256;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < D; base += (int64_t)gridDim.x * 256) {
+        if (threadIdx.x == 0) *nfound = 0;
         __syncthreads();
+        const int64_t d = base + threadIdx.x;
+        if (d < D && status[d] == 1) found[atomicAdd(nfound, 1)] = (int32_t)d;
+        __syncthreads();
+        const int n = *nfound;
+        for (int i = 0; i < n; ++i) {                  // (documents are independent: the order inside a chunk does not matter)
+            logspace_document(p, elog_wk, sstats_extra, found[i], smem);
+            __syncthreads();
+        }
     }
-}
-
-__global__ __launch_bounds__(256) void flagged_collect_kernel(const int32_t* __restrict__ status,
-                                                              int64_t D, int32_t* __restrict__ list,
-                                                              int32_t* __restrict__ count)
-{
-    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (d < D && status[d] == 1) list[atomicAdd(count, 1)] = (int32_t)d;
 }
 
 }  // namespace pylda

@@ -142,8 +142,7 @@ struct pylda_corpus {
     double* d_doc_wll = nullptr;
     int32_t* d_iters = nullptr;
     int32_t* d_status = nullptr;
-    int32_t* d_flag_list = nullptr;
-    int32_t* d_flag_count = nullptr;   // documents the safety net redid in the last E-step over THIS corpus
+    int32_t* d_flag_count = nullptr;   // documents the safety net redid in the last E-step over THIS corpus (in d_scalars[3])
     double* d_scalars = nullptr;   // [0] doc ll, [1] words ll, [2] corpus entropy term (fast path)
     double* d_entropy_partial = nullptr;
     bool last_doc_values = true;

@@ -79,6 +79,31 @@ __global__ __launch_bounds__(256) void row_shift_exp_kernel(double* __restrict__
     if (lane == 0) shift[w] = m;
 }
 
+// The two passes above in one for a SMALL table with K <= 64 (associated-press K = 10: 68 000 entries): one wavefront per
+// word, lane k reads eta[k][w] straight from the topic-major matrix (the strided read costs nothing at this size) -
+// one kernel boundary less in an E-step that is a chain of them.  The same operations in the same order: bitwise the
+// tables of the two-pass path.
+__global__ __launch_bounds__(256) void elog_rows_small_kernel(const double* __restrict__ eta,
+                                                              const double* __restrict__ psi_rowsum, int K, int V, int ldk,
+                                                              double* __restrict__ elog_wk, double* __restrict__ expElog,
+                                                              double* __restrict__ expElog_elog, double* __restrict__ shift)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = blockIdx.x * 4 + threadIdx.x / kWave;
+    if (w >= V) return;
+    const bool real = lane < K;
+    const double raw = real ? digamma(eta[(size_t)lane * V + w]) - psi_rowsum[lane] : -INFINITY;
+    const double m = wave_max(raw);
+    if (lane < ldk) {
+        const double e = real ? raw - m : 0.0;
+        const double b = real ? exp(e) : 0.0;
+        elog_wk[(size_t)w * ldk + lane] = e;
+        expElog[(size_t)w * ldk + lane] = b;
+        expElog_elog[(size_t)w * ldk + lane] = b > 0.0 ? b * e : 0.0;
+    }
+    if (lane == 0) shift[w] = m;
+}
+
 // topic_lse[k] = logsumexp_v (Elog[v][k] + shift[v]); one workgroup per topic.
 __global__ __launch_bounds__(256) void topic_lse_kernel(const double* __restrict__ elog_wk,
                                                         const double* __restrict__ shift, int K,
@@ -107,16 +132,25 @@ __global__ __launch_bounds__(1024) void vector_sum_kernel(const double* __restri
     if (threadIdx.x == 0) out[0] = s;
 }
 
-// The three corpus-level sums of an E-step (document log-likelihood, words log-likelihood, entropy partials of the
-// statistics pass) in one launch: workgroup b sums vector b (a small corpus' E-step is a chain of kernel boundaries).
+// The corpus-level sums of an E-step (document log-likelihood, words log-likelihood, entropy partials of the statistics
+// pass) and the count of documents the log-space safety net redid (status 2) in ONE launch: workgroup b does job b (a
+// small corpus' E-step is a chain of kernel boundaries).
 struct SumJob {
     const double* x;
     int64_t n;
     double* out;
 };
-__global__ __launch_bounds__(1024) void vector_sum3_kernel(SumJob a, SumJob b, SumJob c)
+__global__ __launch_bounds__(1024) void vector_sum3_kernel(SumJob a, SumJob b, SumJob c, const int32_t* __restrict__ status,
+                                                           int64_t D, int32_t* __restrict__ redone)
 {
     __shared__ double scratch[16];
+    if (blockIdx.x == 3) {
+        double n = 0.0;
+        for (int64_t i = threadIdx.x; i < D; i += 1024) n += status[i] == 2 ? 1.0 : 0.0;
+        n = block_sum<1024>(n, scratch);                  // (exact: integers below 2^53)
+        if (threadIdx.x == 0) redone[0] = (int32_t)n;
+        return;
+    }
     const SumJob job = blockIdx.x == 0 ? a : blockIdx.x == 1 ? b : c;
     if (!job.out) return;
     double s = 0.0;
