@@ -130,3 +130,48 @@ def test_launch_train_refuses_a_world_it_was_not_asked_for(monkeypatch):
     monkeypatch.delenv("WORLD_SIZE")
     opt = cli._parse(cli.TRAIN_FLAGS, [], "launch_train")
     assert cli._join_ranks(opt) == (0, 1, 0, None)
+
+
+def _init_shard_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pylda_amd import cli
+    from pylda_amd.variational_bayes import VariationalBayes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vocabulary = ["w%d" % i for i in range(30)]
+    rng = np.random.default_rng(7)
+    documents = [" ".join("w%d" % t for t in rng.integers(0, 34, rng.integers(0, 25))) for _ in range(41)]   # (some empty, some OOV tokens)
+    np.random.seed(100 + rank)                       # only rank 0's stream may matter
+    engine = VariationalBayes(device=0, process_group=None)
+    engine._verbose = False
+    cli._initialize_shard(engine, documents, vocabulary, 4, 0.25, 1.0 / 30, rank, world)
+    ptr, ids, cts = engine._train_csr
+    np.savez(os.path.join(out_dir, "shard%d.npz" % rank), ptr=ptr, ids=ids, cts=cts, eta=engine._eta, D=engine._number_of_documents,
+             bounds=np.array(cli._line_ranges(documents, world)))
+    dist.destroy_process_group()
+
+
+def test_ranks_parse_their_own_lines_and_share_rank_zeros_eta(tmp_path):
+    """launch_train --gpus N start-up on CPU: every rank parses its byte-balanced line range only, the shards put
+    together are the one-process parse, and eta is rank 0's seeded draw (variational_bayes.py:95) on every rank."""
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_init_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    shards = [np.load(tmp_path / ("shard%d.npz" % r)) for r in range(world)]
+    sys.path.insert(0, ROOT)
+    from pylda_amd import _capi
+    vocabulary = ["w%d" % i for i in range(30)]
+    rng = np.random.default_rng(7)
+    documents = [" ".join("w%d" % t for t in rng.integers(0, 34, rng.integers(0, 25))) for _ in range(41)]
+    ptr, ids, cts, dropped = _capi.parse_corpus(documents, vocabulary)
+    assert sum(int(s["D"]) for s in shards) == len(ptr) - 1
+    assert np.array_equal(np.concatenate([s["ids"] for s in shards]), ids)
+    assert np.array_equal(np.concatenate([s["cts"] for s in shards]), cts)
+    assert np.array_equal(np.concatenate([np.diff(s["ptr"]) for s in shards]), np.diff(ptr))
+    np.random.seed(100)
+    eta0 = np.random.gamma(100., 1. / 100., (4, 30))
+    for s in shards:
+        assert np.array_equal(s["eta"], eta0)
+        assert np.array_equal(s["bounds"], shards[0]["bounds"])
