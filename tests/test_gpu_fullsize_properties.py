@@ -20,8 +20,8 @@ CONFIGS = {
 @pytest.fixture(scope="module", params=["cfg3", "cfg4"])
 def cfg3(request):
     """cfg 3: synthetic LDA corpus, 100,000 documents, V=50,000, K=128 (quilt kernels);
-    cfg 4: 1,000,000 documents, V=100,000, K=256 (8-wavefront quad kernels up to 208 distinct terms, wide tiered
-    kernels beyond, incl. the multi-round class for the 29 documents with more than 256 distinct terms).  Same generator, seeds and sizes as bench.py."""
+    cfg 4: 1,000,000 documents, V=100,000, K=256 (8-wavefront quad kernels up to 224 distinct terms on chip, with streamed
+    word slots up to 256, the group-fused streaming kernel for the 29 documents beyond).  Same generator, seeds and sizes as bench.py."""
     import bench
     from pylda_amd import _capi
     from pylda_amd.corpus import corpus_checksum, synthetic_lda_shard
@@ -181,3 +181,34 @@ def test_oracle_check_of_full_size_statistics(cfg3):
     # restore the fixture's state for the tests that follow (the context's statistics are those of the last E-step)
     ctx.estep(c["corpus"])
     assert np.array_equal(ctx.get_sstats(), c["sstats"])
+
+
+def test_heldout_mode_at_full_size(cfg3):
+    """Held-out mode (variational_bayes.py:133-138, :202-204, :216) over the full-size corpus: the inner loop is the
+    training one (same gamma, same iteration counts, bit for bit), the sufficient statistics stay untouched, the corpus
+    value is the sum of the per-document values, and sampled documents - incl. the streamed and the longest classes -
+    match the oracle's words log-likelihood."""
+    from conftest import csr_slice
+    from oracle import c_oracle
+    c = cfg3
+    ctx, corpus = c["ctx"], c["corpus"]
+    before = ctx.get_sstats()
+    ctx.estep(corpus, 50, 1e-6, True)
+    _, words_ll, nlog = ctx.estep_results(corpus)
+    _, doc_wll, iters = ctx.get_doc_values(corpus)
+    gamma = ctx.get_gamma(corpus)
+    assert nlog == 0
+    assert np.array_equal(iters, c["iters"]) and np.array_equal(gamma, c["gamma"])
+    assert np.array_equal(ctx.get_sstats(), before)                      # :216 - the statistics of the training E-step stay
+    assert np.all(np.isfinite(doc_wll)) and np.all(doc_wll < 0)
+    assert abs(doc_wll.sum() - words_ll) < 1e-11 * abs(words_ll)
+    order = np.argsort(np.diff(c["ptr"]))
+    rng = np.random.default_rng(1)
+    docs = np.unique(np.concatenate([rng.choice(c["D"], 10, replace=False), order[:2], order[-3:],
+                                     order[np.searchsorted(np.diff(c["ptr"])[order], [225, 233, 241])]]))
+    ptr, tid, tct = csr_slice(c["ptr"], c["ids"], c["cts"], docs)
+    ref = c_oracle.e_step(c["alpha"], c["eta"], ptr, tid, tct, heldout=True)
+    assert np.array_equal(ref["iters"], iters[docs])
+    assert rel_err(doc_wll[docs], ref["doc_words_ll"]) < 1e-9 and rel_err(gamma[docs], ref["gamma"]) < 1e-9
+    # leave the fixture as the other tests expect it: the training E-step's results
+    ctx.estep(corpus)
