@@ -286,6 +286,7 @@ int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
  *   "wide_postings"  1: 64-bit CSR positions in the postings whatever the corpus size (automatic from 2^31 pairs);
  *   "sweep_xcd"      1 (default): the sweep's rendezvous per XCD (the 32 workgroups that share an L2), 0: chip-wide;
  *   "sweep_spin"     polls of a rendezvous before a workgroup goes on alone (pacing only, never correctness);
+ *   "sweep_sub"      sub-steps the sweep walks a document block's range in (default 4; results are bitwise the same);
  *   "terms_overlap"  1 (default): the document-terms pass of the training fast path runs on an auxiliary stream beside
  *                    the dispatch-paced statistics gather, 0: in front of it;
  *   "launch_order"   1 (default): launch classes with the fewest documents go out first, 0: longest documents first

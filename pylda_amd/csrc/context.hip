@@ -220,6 +220,8 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "sweep_xcd")) {
         ctx->sweep_xcd = value != 0;
+    } else if (!strcmp(name, "sweep_sub")) {
+        ctx->sweep_sub = (int)std::min<int64_t>(64, std::max<int64_t>(1, value));
     } else if (!strcmp(name, "sweep_spin")) {
         ctx->sweep_spin = (int)std::max<int64_t>(0, value);
     } else if (!strcmp(name, "gather_sweep")) {      // (takes effect for corpora whose postings are built afterwards)

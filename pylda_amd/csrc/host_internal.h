@@ -100,6 +100,7 @@ struct pylda_ctx {
     int gather_rows = 2;            // 0: 64-topic chunks; 1: whole rows (ldk 64 / 128 / 256); 2: + postings in bulk (ldk 128 / 256)
     int gather_blocks = -1;         // document blocks of the gather: -1 automatic, 0 / 1 off, n forced (multiple of 8)
     int sweep_xcd = 1;              // the sweep's rendezvous per XCD (32 workgroups) instead of chip-wide (256)
+    int sweep_sub = 4;              // sub-blocks a document block is walked in by the sweep (L2 working set 1 / sub of a block)
     int sweep_spin = 4000;          // polls of a rendezvous of the sweep before a workgroup goes on alone
     int gather_sweep = 1;           // the persistent sweep (sstats_sweep.h) at stride 128 / 256: 0 never, 1 when the partial rows of the
                                     // dispatch-paced gather would exceed their budget (rounds), 2 whenever the gather is blocked

@@ -329,6 +329,12 @@ bool sweep_wanted(const GatherConfig& g, int NB, bool resident)
     return resident && (g.gather_sweep == 2 || rows_bytes > decision_budget(g));
 }
 
+int sweep_blocks(const GatherConfig& g, int NB)
+{
+    if (g.gather_blocks > 1 || NB <= 8) return NB;          // forced, or nothing to merge
+    return std::max(8, NB * 2 / 3 / 8 * 8);
+}
+
 namespace {
 
 // the terms whose postings start in thread t's 1 / nthreads share of the posting range, on multiples of 16 terms

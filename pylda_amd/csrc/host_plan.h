@@ -103,6 +103,9 @@ struct SweepGeom { int T, WPB, passes; };
 SweepGeom sweep_geometry(const GatherConfig& g);
 // the persistent sweep instead of partial rows? (resident: its geometry fits one workgroup per CU)
 bool sweep_wanted(const GatherConfig& g, int NB, bool resident);
+// document blocks of the SWEEP given the gather's: two thirds - it walks a block's document range in sub-steps (sstats_sweep.h),
+// so larger blocks cost no locality and a third of the rendezvous go (cfg 4: 240 blocks 38.6 ms, 160 36.2, 120 37.0)
+int sweep_blocks(const GatherConfig& g, int NB);
 
 // One host thread's share of the segment cut: the segments of a contiguous range of terms.
 struct CutPiece {

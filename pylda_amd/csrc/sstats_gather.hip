@@ -158,7 +158,7 @@ int build_postings(pylda_corpus* c)
     timer.lap("postings on the device");
 
     const GatherConfig g = gather_config(ctx, c);
-    const int NB = document_blocks(g);
+    int NB = document_blocks(g);
     // (the gather kernel family is fixed here, with the postings: the partial rows, the rounds and seg_lo are sized for it,
     //  so a later change of the option must not change the kernel that walks them)
     c->gather_rows = ctx->gather_rows;
@@ -173,7 +173,8 @@ int build_postings(pylda_corpus* c)
         PYLDA_SWEEP_DISPATCH(ctx, c, SWEEP_OCC);
 #undef SWEEP_OCC
     }
-    const bool want_sweep = sweep_wanted(g, NB, per_cu >= 1);
+    const bool want_sweep = sweep_wanted(g, document_blocks(g), per_cu >= 1);
+    if (want_sweep) NB = sweep_blocks(g, NB);
 
     SegmentCut cut;
     if (NB > 1) {
@@ -267,6 +268,8 @@ static void fill_sweep_params(pylda_ctx* ctx, pylda_corpus* c, SweepParams& sp)
     sp.NB = c->gather_blocks;
     sp.rendezvous = c->d_rendezvous;
     sp.per_xcd = ctx->sweep_xcd;
+    sp.per_block = (int)((c->D + c->gather_blocks - 1) / std::max(1, c->gather_blocks));
+    sp.sub = std::max(1, ctx->sweep_sub);
     sp.spin_limit = (unsigned)ctx->sweep_spin;       // (4000 ~ 5 ms: a rendezvous that does not complete costs L2 locality, nothing else)
 }
 

@@ -62,6 +62,8 @@ struct SweepParams {
     unsigned* rendezvous;           // kSweepCounters counters, 32 words apart, zeroed before the launch
     int per_xcd;                    // 1: the workgroups of an XCD meet among themselves (the L2 they share is what the pacing is for)
     unsigned spin_limit;
+    int per_block;                  // documents per document block
+    int sub;                        // sub-blocks a block's document range is walked in (see sweep_rows)
 };
 
 // All workgroups of the grid meet (pacing only): bounded, no memory ordering implied.
@@ -78,17 +80,19 @@ __device__ __forceinline__ void sweep_rendezvous(unsigned* counter, unsigned tar
     __syncthreads();
 }
 
-// acc += sum over the n postings held one per lane (document d, factor r), U rows in flight
+// acc += sum over the postings held one per lane (document d, factor r) in lanes [from, to), U rows in flight
 template <int NP, int U>
-__device__ __forceinline__ void sweep_rows(f64x2 (&acc)[NP], const double* __restrict__ tfinal, int ldk, int lane, int d, double r, int n)
+__device__ __forceinline__ void sweep_rows(f64x2 (&acc)[NP], const double* __restrict__ tfinal, int ldk, int lane, int d, double r, int from,
+                                           int to)
 {
-    for (int q = 0; q < n; q += U) {
+    for (int q = from; q < to; q += U) {
         f64x2 row[U][NP];
         double rr[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {                           // (lanes past n hold document 0 and r = 0)
-            const int doc = __builtin_amdgcn_readlane(d, (q + u) & (kWave - 1));
-            rr[u] = q + u < kWave ? readlane_f64(r, (q + u) & (kWave - 1)) : 0.0;
+        for (int u = 0; u < U; ++u) {                           // (past the range: the range's first row again, factor 0)
+            const int at = q + u < to ? q + u : from;
+            const int doc = __builtin_amdgcn_readlane(d, at & (kWave - 1));
+            rr[u] = q + u < to ? readlane_f64(r, at & (kWave - 1)) : 0.0;
             const f64x2* src = reinterpret_cast<const f64x2*>(tfinal + (size_t)doc * ldk) + lane;
 #pragma unroll
             for (int j = 0; j < NP; ++j) row[u][j] = src[64 * j];
@@ -99,6 +103,36 @@ __device__ __forceinline__ void sweep_rows(f64x2 (&acc)[NP], const double* __res
             for (int j = 0; j < NP; ++j) {
                 acc[j].x = fma(rr[u], row[u][j].x, acc[j].x);
                 acc[j].y = fma(rr[u], row[u][j].y, acc[j].y);
+            }
+    }
+}
+
+// The same for TWO terms side by side, two rows each per trip: a sub-step of a block leaves a term ~2 postings, and four
+// rows in flight per wavefront are what hides the round trip.  Each accumulator still sees its postings in lane order.
+template <int NP>
+__device__ __forceinline__ void sweep_rows_pair(f64x2 (&accA)[NP], f64x2 (&accB)[NP], const double* __restrict__ tfinal, int ldk, int lane,
+                                                int dA, double rA, int fromA, int toA, int dB, double rB, int fromB, int toB)
+{
+    for (int qa = fromA, qb = fromB; qa < toA || qb < toB; qa += 2, qb += 2) {
+        f64x2 row[4][NP];
+        double rr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                           // (past a range: document 0, factor 0)
+            const int at = u < 2 ? qa + u : qb + u - 2;
+            const bool valid = u < 2 ? at < toA : at < toB;
+            const int doc = valid ? __builtin_amdgcn_readlane(u < 2 ? dA : dB, at & (kWave - 1)) : 0;
+            rr[u] = valid ? readlane_f64(u < 2 ? rA : rB, at & (kWave - 1)) : 0.0;
+            const f64x2* src = reinterpret_cast<const f64x2*>(tfinal + (size_t)doc * ldk) + lane;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) row[u][j] = src[64 * j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                f64x2& a = u < 2 ? accA[j] : accB[j];
+                a.x = fma(rr[u], row[u][j].x, a.x);
+                a.y = fma(rr[u], row[u][j].y, a.y);
             }
     }
 }
@@ -151,10 +185,32 @@ __global__ __launch_bounds__(kWave* WPB) void sstats_sweep_kernel(SweepParams p)
                 }
 #pragma unroll
                 for (int x = 0; x < GS; ++x) r[x] = lane < n[x] ? p.rfinal[pos[x]] : 0.0;      // stage 3: r
+                // stage 4: rows.  A block's t rows (cfg 4: 8.5 MB) do not fit an XCD's L2 (4 MB) - 63 % of the rows came
+                // over the fabric, at its rate - so the block's document range is walked in `sub` steps: a term's postings are
+                // in document order, the lanes below the step's bound are a prefix, and all wavefronts of the XCD move
+                // through the block roughly together with a working set of 1 / sub of it.  Same postings in the same order
+                // per accumulator: bitwise the one-step result.
+                int done[GS];
 #pragma unroll
-                for (int x = 0; x < GS; ++x) {                          // stage 4: rows
+                for (int x = 0; x < GS; ++x) done[x] = 0;
+                for (int step = 1; step <= p.sub; ++step) {
+                    const int bound = step == p.sub ? 0x7fffffff : b * p.per_block + (int)((int64_t)p.per_block * step / p.sub);
+                    int upto[GS];
+#pragma unroll
+                    for (int x = 0; x < GS; ++x)
+                        upto[x] = n[x] > done[x] ? __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < n[x] && d[x] < bound)) : done[x];
+#pragma unroll
+                    for (int x = 0; x < GS; x += 2) {
+                        if (upto[x] > done[x] || upto[x + 1] > done[x + 1])
+                            sweep_rows_pair<NP>(acc[i0 + x], acc[i0 + x + 1], p.tfinal, ldk, lane, d[x], r[x], done[x], upto[x], d[x + 1],
+                                                r[x + 1], done[x + 1], upto[x + 1]);
+                        done[x] = upto[x];
+                        done[x + 1] = upto[x + 1];
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < GS; ++x) {
                     if (n[x] > 0) {
-                        sweep_rows<NP, U>(acc[i0 + x], p.tfinal, ldk, lane, d[x], r[x], n[x]);
                         ++cs[i0 + x];
                         nb[i0 + x] = cs[i0 + x] < hi[i0 + x] ? p.seg_block[cs[i0 + x]] : 0x7fffffff;
                     }
@@ -169,7 +225,7 @@ __global__ __launch_bounds__(kWave* WPB) void sstats_sweep_kernel(SweepParams p)
                     const bool mine = lane < m;
                     const int dd = mine ? p.post_doc[s0 + lane] : 0;
                     const double rr = mine ? p.rfinal[post_pos[s0 + lane]] : 0.0;
-                    sweep_rows<NP, U>(acc[i], p.tfinal, ldk, lane, dd, rr, m);
+                    sweep_rows<NP, U>(acc[i], p.tfinal, ldk, lane, dd, rr, 0, m);
                     ++cs[i];
                     nb[i] = cs[i] < hi[i] ? p.seg_block[cs[i]] : 0x7fffffff;
                 }

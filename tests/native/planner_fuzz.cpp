@@ -138,6 +138,8 @@ static int check_statistics_plan()
     const SweepGeom sg = sweep_geometry(g);
     REQUIRE((int64_t)sg.passes * g.num_cu * sg.WPB * sg.T >= g.V, "the sweep's geometry holds every term");
     (void)sweep_wanted(g, automatic, true);
+    const int swept = sweep_blocks(g, automatic);
+    REQUIRE(swept >= 1 && swept <= automatic && (swept == automatic || swept % 8 == 0), "sweep blocks %d of %d", swept, automatic);
 
     // ---- blocked cut ----
     const int NB = 8 * rnd_in(1, 9);

@@ -569,8 +569,10 @@ def test_statistics_gather_as_a_persistent_sweep(capi, ap_train, K, blocks, wide
     assert abs(got[1][0][0].sum() - tct.sum()) < 1e-7
     assert np.array_equal(got[1][0][0], got[1][1][0]) and got[1][0][1] == got[1][1][1]
     # pacing and scheduling options change WHEN things run, never a bit of the result: the sweep's rendezvous per XCD or
-    # chip-wide, the document-terms pass beside the gather or in front of it, the launch order of the classes
+    # chip-wide, the sub-steps it walks a block in, the document-terms pass beside the gather or in front of it, the
+    # launch order of the classes
     for options in ([("gather_sweep", 2), ("sweep_xcd", 0)], [("terms_overlap", 0)], [("launch_order", 0)],
+                    [("gather_sweep", 2), ("sweep_sub", 1)], [("gather_sweep", 2), ("sweep_sub", 7)],     # sub-steps of a block
                     [("terms_overlap", 0), ("launch_order", 0), ("gather_sweep", 2), ("sweep_xcd", 0)]):
         ctx = capi.Context(K, 6806)
         ctx.set_option("gather_blocks", blocks)
