@@ -17,6 +17,7 @@
 #include "estep_common.h"
 #include "estep_qfuse.h"
 #include "special_device.h"
+#include "estep_epilogue.h"
 #include "estep_limits.h"
 
 namespace pylda {
@@ -351,60 +352,14 @@ __global__ __launch_bounds__(512, 2) void estep_qfusek_kernel(EstepParams p)
             else p.rfinal[lo + n] = r;
         }
     }
-    double term2 = 0.0, lse_term = 0.0, lgam = 0.0, gsum = 0.0;
+    TopicShare share;
 #pragma unroll
     for (int u = 0; u < TPT; ++u) {
         const int k = tid + u * NT;
-        if (topic_live[u]) {
-            const double t_last = tt[last * KT + k];
-            const double mass = gam[u] - alf[k];
-            const double ltv = digamma(gpv[k]) - psi_total;
-            term2 = fma(ltv, mass, term2);
-            if (p.heldout) lse_term = fma(p.topic_lse[k], mass, lse_term);
-            lgam += lgamma_pos(gam[u]);
-            gsum += gam[u];
-            p.gamma[(size_t)doc * K + k] = gam[u];
-            if (!p.heldout) p.tfinal[(size_t)doc * ldk + k] = t_last;
-        } else if (topic_thread[u] && !p.heldout) {
-            p.tfinal[(size_t)doc * ldk + k] = 0.0;
-        }
+        if (topic_thread[u])
+            topic_share(p, doc, k, ldk, topic_live[u], true, gam[u], alf[k], gpv[k], tt[last * KT + k], psi_total, share);
     }
-    term1 = wave_sum(term1);
-    term2 = wave_sum(term2);
-    lse_term = wave_sum(lse_term);
-    lgam = wave_sum(lgam);
-    gsum = wave_sum(gsum);
-    term3 = wave_sum(term3);
-    shift_term = wave_sum(shift_term);
-    __syncthreads();
-    if (c == 0) {
-        misc[0 * W + wave] = term1;
-        misc[1 * W + wave] = term2;
-        misc[2 * W + wave] = lse_term;
-        misc[3 * W + wave] = lgam;
-        misc[4 * W + wave] = gsum;
-        misc[5 * W + wave] = term3;
-        misc[6 * W + wave] = shift_term;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double t1 = 0.0, t2 = 0.0, tl = 0.0, lg = 0.0, gs = 0.0, t3 = 0.0, sh = 0.0;
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-            t1 += misc[0 * W + w];
-            t2 += misc[1 * W + w];
-            tl += misc[2 * W + w];
-            lg += misc[3 * W + w];
-            gs += misc[4 * W + w];
-            t3 += misc[5 * W + w];
-            sh += misc[6 * W + w];
-        }
-        const double ent = t1 + t2 - t3;
-        p.doc_ll[doc] = p.alpha_term + lg - lgamma_pos(gs) - ent;        // :195-199
-        p.doc_words_ll[doc] = p.heldout ? t1 + sh - tl : 0.0;            // :204
-        p.iters[doc] = it;
-        p.status[doc] = 0;
-    }
+    finish_document<W>(p, doc, it, misc, c, wave, tid, term1, term3, shift_term, share);
 }
 
 }  // namespace pylda

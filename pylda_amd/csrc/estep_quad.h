@@ -37,6 +37,7 @@
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
+#include "estep_epilogue.h"
 
 namespace pylda {
 
@@ -589,55 +590,10 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         if (owner0) p.rfinal[lo + word0] = r0;
         if (owner1) p.rfinal[lo + word1] = r1;
     }
-    double term2 = 0.0, lse_term = 0.0, lgam = 0.0, gsum = 0.0;
-    if (topic_live) {
-        const double t_last = tt[last * KT + ktid], alpha_k = alf[ktid];
-        const double mass = gam - alpha_k;                                // = t_last * s
-        const double ltv = digamma(gpv[ktid]) - psi_total;                // log t of the last iteration
-        term2 = ltv * mass;
-        if (p.heldout) lse_term = p.topic_lse[ktid] * mass;
-        lgam = lgamma_pos(gam);
-        gsum = gam;
-        p.gamma[(size_t)doc * K + ktid] = gam;
-        if (!p.heldout) p.tfinal[(size_t)doc * ldk + ktid] = t_last;
-    } else if (topic_thread && !p.heldout) {
-        p.tfinal[(size_t)doc * ldk + ktid] = 0.0;
-    }
-    term1 = wave_sum(term1);
-    term2 = wave_sum(term2);
-    lse_term = wave_sum(lse_term);
-    lgam = wave_sum(lgam);
-    gsum = wave_sum(gsum);
-    term3 = wave_sum(term3);
-    shift_term = wave_sum(shift_term);
-    if (lane == 0) {
-        misc[0 * W + wave] = term1;
-        misc[1 * W + wave] = term2;
-        misc[2 * W + wave] = lse_term;
-        misc[3 * W + wave] = lgam;
-        misc[4 * W + wave] = gsum;
-        misc[5 * W + wave] = term3;
-        misc[6 * W + wave] = shift_term;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double t1 = 0.0, t2 = 0.0, tl = 0.0, lg = 0.0, gs = 0.0, t3 = 0.0, sh = 0.0;
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-            t1 += misc[0 * W + w];
-            t2 += misc[1 * W + w];
-            tl += misc[2 * W + w];
-            lg += misc[3 * W + w];
-            gs += misc[4 * W + w];
-            t3 += misc[5 * W + w];
-            sh += misc[6 * W + w];
-        }
-        const double ent = t1 + t2 - t3;
-        p.doc_ll[doc] = p.alpha_term + lg - lgamma_pos(gs) - ent;        // :195-199
-        p.doc_words_ll[doc] = p.heldout ? t1 + sh - tl : 0.0;            // :204
-        p.iters[doc] = it;
-        p.status[doc] = 0;
-    }
+    TopicShare share;
+    if (topic_thread)
+        topic_share(p, doc, ktid, ldk, topic_live, true, gam, alf[ktid], gpv[ktid], tt[last * KT + ktid], psi_total, share);
+    finish_document<W>(p, doc, it, misc, lane, wave, tid, term1, term3, shift_term, share);
 }
 
 }  // namespace pylda

@@ -24,6 +24,7 @@
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
+#include "estep_epilogue.h"
 
 namespace pylda {
 
@@ -296,56 +297,11 @@ __global__ __launch_bounds__(kWave* W) void estep_quilt_kernel(EstepParams p)
     const bool word_owner = word_live && (c % LPW) == 0;
     double term3 = word_owner ? my_cnt * log(nrm_mine) : 0.0;
     double shift_term = (word_owner && p.heldout) ? my_cnt * p.shift[p.term_id[lo + my_word]] : 0.0;
-    double term2 = 0.0, lse_term = 0.0, lgam = 0.0, gsum = 0.0;
-    if (topic_live) {
-        const double t_last = tt[last * KT + tid];
-        const double moved = gam - alpha_k;                               // = t_last * s
-        const double ltv = digamma(gam_prev) - psi_total;                 // log t of the last iteration
-        term2 = ltv * moved;
-        if (p.heldout) lse_term = p.topic_lse[tid] * moved;
-        lgam = lgamma_pos(gam);
-        gsum = gam;
-        p.gamma[(size_t)doc * K + tid] = gam;
-        if (!p.heldout) p.tfinal[(size_t)doc * ldk + tid] = t_last;
-    } else if (topic_thread && !p.heldout) {
-        p.tfinal[(size_t)doc * ldk + tid] = 0.0;
-    }
+    TopicShare share;
+    if (topic_thread)
+        topic_share(p, doc, tid, ldk, topic_live, true, gam, alpha_k, gam_prev, tt[last * KT + tid], psi_total, share);
     if (word_owner && !p.heldout) p.rfinal[lo + my_word] = r_mine;
-    term1 = wave_sum(term1);
-    term2 = wave_sum(term2);
-    lse_term = wave_sum(lse_term);
-    lgam = wave_sum(lgam);
-    gsum = wave_sum(gsum);
-    term3 = wave_sum(term3);
-    shift_term = wave_sum(shift_term);
-    if (lane == 0) {
-        misc[0 * W + wave] = term1;
-        misc[1 * W + wave] = term2;
-        misc[2 * W + wave] = lse_term;
-        misc[3 * W + wave] = lgam;
-        misc[4 * W + wave] = gsum;
-        misc[5 * W + wave] = term3;
-        misc[6 * W + wave] = shift_term;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double t1 = 0.0, t2 = 0.0, tl = 0.0, lg = 0.0, gs = 0.0, t3 = 0.0, sh = 0.0;
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-            t1 += misc[0 * W + w];
-            t2 += misc[1 * W + w];
-            tl += misc[2 * W + w];
-            lg += misc[3 * W + w];
-            gs += misc[4 * W + w];
-            t3 += misc[5 * W + w];
-            sh += misc[6 * W + w];
-        }
-        const double ent = t1 + t2 - t3;
-        p.doc_ll[doc] = p.alpha_term + lg - lgamma_pos(gs) - ent;        // :195-199
-        p.doc_words_ll[doc] = p.heldout ? t1 + sh - tl : 0.0;            // :204
-        p.iters[doc] = it;
-        p.status[doc] = 0;
-    }
+    finish_document<W>(p, doc, it, misc, lane, wave, tid, term1, term3, shift_term, share);
 }
 
 }  // namespace pylda
