@@ -290,3 +290,42 @@ def test_shards_of_a_corpus_smaller_than_the_world():
         assert sp[0] == 0 and sp[-1] == si.size == sc.size and len(sp) == hi - lo + 1
         seen += hi - lo
     assert seen == 2
+
+
+def test_traffic_hash_covers_every_device_header_of_the_estep():
+    """The other direction of the guard: every csrc header that defines a kernel (or device code a kernel inlines) and is
+    included - directly or through other headers - by the translation units that launch the E-step's kernels must be part
+    of bench.kernel_source_hash(); a new kernel header with a name the hash does not match would otherwise let a stale
+    profiles/traffic_*.json pass as current."""
+    import os
+    import re
+    import bench
+    csrc = os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "pylda_amd", "csrc")
+    hashed = {f for f in os.listdir(csrc)
+              if f.endswith(".h") and (f.startswith("estep_") or f.startswith("sstats_") or f in ("doc_terms.h", "special_device.h", "prepare_kernels.h"))}
+
+    def includes(name, seen):
+        for inc in re.findall(r'#include "([^"/]+)"', open(os.path.join(csrc, name)).read()):
+            if inc not in seen and os.path.exists(os.path.join(csrc, inc)):
+                seen.add(inc)
+                includes(inc, seen)
+        return seen
+
+    reached = set()
+    for unit in ("estep_api.hip", "launch_small.hip", "launch_quad.hip", "launch_stream.hip", "sstats_gather.hip"):
+        includes(unit, reached)
+    device = {h for h in reached if re.search(r"__global__|__device__", open(os.path.join(csrc, h)).read())}
+    host_side = {"host_internal.h", "host_plan.h", "comm.h", "postings.h"}          # declarations only / host code
+    assert device - host_side <= hashed, sorted(device - host_side - hashed)
+    # ... and the hash really reads them: touching a copy of each changes it
+    import shutil, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = os.path.join(tmp, "csrc")
+        shutil.copytree(csrc, copy)
+        base = bench.kernel_source_hash(copy)
+        for h in sorted(device - host_side):
+            with open(os.path.join(copy, h), "a") as fh:
+                fh.write("// edit\n")
+            now = bench.kernel_source_hash(copy)
+            assert now != base, h
+            base = now
