@@ -49,7 +49,7 @@ typedef enum pylda_status {
  *      pylda_set_stream(NULL) = HIP's null stream (pylda_use_own_stream restores the private one)
  *   3  additions only: pylda_abi_version, pylda_mstep_enqueue / pylda_outer_device / pylda_allreduce_outer /
  *      pylda_outer_fetch (one host wait per outer iteration), pylda_model_checkpoint, pylda_mark_time /
- *      pylda_elapsed_ms, pylda_work_counters, pylda_host_alloc / pylda_host_free, pylda_test_alpha_update;
+ *      pylda_elapsed_ms, pylda_work_counters, pylda_executed_work, pylda_host_alloc / pylda_host_free, pylda_test_alpha_update;
  *      pylda_set_alpha no longer waits for the stream (and is a no-op when handed the values the device holds)
  * A host compiled against another version must refuse to run: compare PYLDA_ABI_VERSION with
  * pylda_abi_version() right after loading the library. */
@@ -235,6 +235,12 @@ int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, double* sstats_kern
  * actually ran (sum_d I_d) and their terms (sum_d I_d N_d: 4 K flops each, :177-185).  Returns and resets them
  * (synchronises). */
 int pylda_work_counters(pylda_ctx* ctx, double* inner_iterations, double* inner_iteration_terms);
+/* ... and what the kernels really ran (same accumulation, same reset; call it right BEHIND pylda_work_counters - the two
+ * share one read of the device counters): tile_entries = sum_d N_d (K x iterations of the dense kernel + tile columns x
+ * iterations of the live-topic kernel) - two FMAs each - and the documents handed to the live-topic kernel
+ * (estep_compact.h: the iterations of :174-190 on the topics whose gamma still differs from alpha).
+ * tile_entries / (K x inner_iteration_terms) is the fraction of the dense N_d x K work that was executed. */
+int pylda_executed_work(pylda_ctx* ctx, double* tile_entries, double* handed_over);
 
 /* The launch schedule of a corpus: documents are bucketed by distinct-term
  * count into launch classes (one kernel instantiation each; the classes of one
@@ -292,6 +298,12 @@ int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
  *   "launch_order"   1 (default): launch classes with the fewest documents go out first, 0: longest documents first
  *                    (scheduling options never change a bit of the results);
  *   "slab_uber"      1 (default): the slab launch classes of a small corpus go out as one dispatch;
+ *   "compact"        1 (default): at 64 < K <= 256 a document leaves the dense kernel once few enough topics still move
+ *                    (gamma_k != alpha_k bitwise; 20-32 by document length) and finishes on the live-topic kernel; 0: dense
+ *                    kernels only.  Same iteration counts, results equal to rounding (another summation order);
+ *   "compact_cap"    test hook: hand over at this many live topics at most (0: the kernel's capacity; <= 32);
+ *   "compact_guard_fail" test hook: the live-topic kernel's exactness guard fails for every document (they are redone by
+ *                    the log-space kernel);
  *   "quad" (1: documents of <= 224 distinct terms at 64 < K <= 256 run on the quad kernel), "quad_stream" (1: ... and
  *   those of 225-256 terms too, with word slots streamed from the table), "quilt_odd",
  *   "quilt12", "lds_pad"  A/B switches of kernel geometry ("Tried and measured"). */

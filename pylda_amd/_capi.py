@@ -70,6 +70,7 @@ SIGNATURES = {
     "pylda_mark_time": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pylda_elapsed_ms": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _c_double_p]),
     "pylda_work_counters": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
+    "pylda_executed_work": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
     "pylda_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pylda_kernel_time": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_int64_p]),
     "pylda_corpus_layout": (ctypes.c_int64, [_vp, ctypes.c_char_p]),
@@ -448,6 +449,13 @@ class Context(object):
         """(sum_d I_d, sum_d I_d N_d) of the profiled E-steps since the last call."""
         a, b = ctypes.c_double(0), ctypes.c_double(0)
         self._check(self._lib.pylda_work_counters(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def executed_work(self):
+        """(tile entries the kernels ran through the FMA pipes, documents handed to the live-topic kernel) of the same
+        E-steps: call right behind work_counters() (one read of the device counters serves both)."""
+        a, b = ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.pylda_executed_work(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
     # ---- device-resident interop ----

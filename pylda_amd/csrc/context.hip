@@ -133,8 +133,8 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     CREATE_TRY(dev_alloc(ctx, &ctx->d_partial, (size_t)1024 * K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_outer, (size_t)(3 * K + 8)));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_newton_work, (size_t)4 * K));
-    CREATE_TRY(dev_alloc(ctx, &ctx->d_work, (size_t)2));
-    CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_work, 0, 2 * sizeof(double), ctx->stream), "hipMemsetAsync"));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_work, (size_t)4));
+    CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_work, 0, 4 * sizeof(double), ctx->stream), "hipMemsetAsync"));
     CREATE_TRY(hip_ok(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), (size_t)(5 * K + 8) * sizeof(double), hipHostMallocDefault),
                       "hipHostMalloc"));
     for (int i = 0; i < 2; ++i)
@@ -249,6 +249,13 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "doc_values")) {
         ctx->doc_values = value != 0;
+    } else if (!strcmp(name, "compact")) {
+        ctx->compact = value != 0;
+    } else if (!strcmp(name, "compact_cap")) {
+        if (value < 0 || value > kLiveStride) return fail(ctx, PYLDA_ERR_INVALID, "compact_cap=%lld: 0 .. %d", (long long)value, kLiveStride);
+        ctx->compact_cap = (int)value;
+    } else if (!strcmp(name, "compact_guard_fail")) {
+        ctx->compact_guard_fail = value != 0;
     } else
         return fail(ctx, PYLDA_ERR_INVALID, "unknown option '%s'", name);
     return PYLDA_OK;
@@ -416,16 +423,42 @@ int pylda_elapsed_ms(pylda_ctx* ctx, int slot_from, int slot_to, double* ms)
     return PYLDA_OK;
 }
 
+namespace {
+// the four work counters of the profiled E-steps since the last read (doc_terms.h work_count_kernel), read and reset
+int fetch_work(pylda_ctx* ctx, double (&w)[4])
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->work_cached) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->work_cache, ctx->d_work, sizeof ctx->work_cache, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof ctx->work_cache, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    for (int i = 0; i < 4; ++i) w[i] = ctx->work_cache[i];
+    return PYLDA_OK;
+}
+}  // namespace
+
 int pylda_work_counters(pylda_ctx* ctx, double* inner_iterations, double* inner_iteration_terms)
 {
     if (!ctx) return PYLDA_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    double w[2] = {0.0, 0.0};
-    HIP_TRY(ctx, hipMemcpyAsync(w, ctx->d_work, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof w, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double w[4];
+    const int rc = fetch_work(ctx, w);
+    if (rc != PYLDA_OK) return rc;
+    ctx->work_cached = true;            // (pylda_executed_work reports the other half of the same read)
     if (inner_iterations) *inner_iterations = w[0];
     if (inner_iteration_terms) *inner_iteration_terms = w[1];
+    return PYLDA_OK;
+}
+
+int pylda_executed_work(pylda_ctx* ctx, double* tile_entries, double* handed_over)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    double w[4];
+    const int rc = fetch_work(ctx, w);
+    if (rc != PYLDA_OK) return rc;
+    ctx->work_cached = false;
+    if (tile_entries) *tile_entries = w[2];
+    if (handed_over) *handed_over = w[3];
     return PYLDA_OK;
 }
 

@@ -56,23 +56,37 @@ __global__ __launch_bounds__(256) void doc_terms_kernel(EstepParams p, int64_t c
     }
 }
 
-// Profiling: work[0] += sum_d I_d, work[1] += sum_d I_d N_d (inner iterations executed, and their terms) - single
-// workgroup, so the accumulation over E-steps needs no atomics.
+// Profiling: work[0] += sum_d I_d, work[1] += sum_d I_d N_d (inner iterations executed, and their terms), work[2] +=
+// sum_d N_d (K x dense iterations + tile columns x live-topic iterations) (the tile entries the kernels really ran
+// through the FMA pipes, twice per iteration), work[3] += documents handed to the live-topic kernel - single workgroup,
+// so the accumulation over E-steps needs no atomics.
 __global__ __launch_bounds__(1024) void work_count_kernel(const int32_t* __restrict__ iters, const int64_t* __restrict__ doc_ptr,
-                                                          int64_t D, double* __restrict__ work)
+                                                          int64_t D, double* __restrict__ work, const int32_t* __restrict__ handoff_it,
+                                                          const int32_t* __restrict__ col_iters, int K)
 {
     __shared__ double scratch[16];
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0, e = 0.0, h = 0.0;
     for (int64_t d = threadIdx.x; d < D; d += 1024) {
-        const double it = (double)iters[d];
+        const double it = (double)iters[d], n = (double)(doc_ptr[d + 1] - doc_ptr[d]);
         a += it;
-        b += it * (double)(doc_ptr[d + 1] - doc_ptr[d]);
+        b += it * n;
+        const int at = handoff_it ? handoff_it[d] : -1;
+        if (at >= 0) {
+            e += n * ((double)K * at + (double)col_iters[d]);
+            h += 1.0;
+        } else {
+            e += n * (double)K * it;
+        }
     }
     a = block_sum<1024>(a, scratch);
     b = block_sum<1024>(b, scratch);
+    e = block_sum<1024>(e, scratch);
+    h = block_sum<1024>(h, scratch);
     if (threadIdx.x == 0) {
         work[0] += a;
         work[1] += b;
+        work[2] += e;
+        work[3] += h;
     }
 }
 

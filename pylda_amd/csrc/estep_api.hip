@@ -122,6 +122,7 @@ int pylda_corpus_create(pylda_ctx* ctx, int64_t D, const int64_t* doc_ptr, const
     c->h_terms_sorted.resize((size_t)D);
     for (int64_t i = 0; i < D; ++i)
         c->h_terms_sorted[i] = (int32_t)(doc_ptr[order[i] + 1] - doc_ptr[order[i]]);
+    c->h_order = order;
     build_plan(c);
     timer.lap("schedule (sort + launch plan)");
 
@@ -180,6 +181,8 @@ void pylda_corpus_destroy(pylda_corpus* c)
     c->d_post_pos = nullptr;
     dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial); dev_free(c->d_exec_order);
     dev_free(c->d_seg_block); dev_free(c->d_term_of); dev_free(c->d_rendezvous);
+    dev_free(c->d_live_n); dev_free(c->d_live_idx); dev_free(c->d_tile_ptr); dev_free(c->d_live_tile);
+    dev_free(c->d_handoff_it); dev_free(c->d_col_iters);
     delete c;
 }
 
@@ -254,6 +257,21 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
                 p.term_scratch = c->d_term_scratch;
                 break;
             }
+    // hand-over to the live-topic kernel (estep_compact.h): buffers, and the per-document work counters of this E-step
+    if ((rc = prepare_compact(ctx, c)) != PYLDA_OK) return rc;
+    p.handoff_live = 0;
+    p.live_n = c->d_live_n;
+    p.live_idx = c->d_live_idx;
+    p.live_tile = c->d_live_tile;
+    p.tile_ptr = c->d_tile_ptr;
+    p.handoff_it = c->d_handoff_it;
+    p.col_iters = c->d_col_iters;
+    p.alpha_max = *std::max_element(ctx->h_alpha.begin(), ctx->h_alpha.end());
+    p.alpha_min = ctx->compact_guard_fail ? 0.0 : *std::min_element(ctx->h_alpha.begin(), ctx->h_alpha.end());
+    if (c->compact_ready) {
+        HIP_TRY(ctx, hipMemsetAsync(c->d_handoff_it, 0xff, (size_t)c->D * sizeof(int32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(c->d_col_iters, 0, (size_t)c->D * sizeof(int32_t), ctx->stream));
+    }
     auto open_bracket = [&](int slot, hipStream_t st) -> int {      // index into pending_events, or -1
         if (!ctx->profiling) return -1;
         pylda_ctx::Bracket br{take_event(ctx), take_event(ctx), slot};
@@ -303,7 +321,11 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             p.order = c->d_order + L.first;
             p.n_cap = L.n_cap;
             p.tile_stride = L.tile_stride;
+            p.handoff_live = c->compact_ready ? compact_handoff_for(ctx, L) : 0;
             const int class_bracket = open_bracket(slot, ctx->stream);
+            if (getenv("PYLDA_DEBUG_SYNC"))
+                fprintf(stderr, "[pylda debug] launching class %d variant %d geometry %d documents %lld n_cap %d handoff %d\n", slot, L.variant, L.rn,
+                        (long long)L.count, L.n_cap, p.handoff_live);
             switch (L.variant) {
             case kSlab: rc = launch_slab_any(ctx, p, L); break;
             case kQuilt: rc = launch_quilt_any(ctx, p, L); break;
@@ -313,6 +335,18 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kQfusek: rc = launch_qfusek(ctx, p, L); break;
             default: rc = launch_generic_any(ctx, p, L); break;      // the generic family (tile in LDS / re-read from the table)
             }
+            static const bool debug_sync = getenv("PYLDA_DEBUG_SYNC") != nullptr;      // (fault localisation: wait after every launch)
+            if (debug_sync) {
+                const hipError_t e = hipStreamSynchronize(ctx->stream);
+                fprintf(stderr, "[pylda debug] class %d variant %d geometry %d documents %lld handoff %d: %s\n", slot, L.variant, L.rn,
+                        (long long)L.count, p.handoff_live, hipGetErrorString(e));
+            }
+            // ... and behind it, on the same stream, the live-topic kernel for the documents the class handed over
+            if (rc == PYLDA_OK && p.handoff_live > 0) rc = launch_compact(ctx, p, L);
+            if (debug_sync && p.handoff_live > 0) {
+                const hipError_t e = hipStreamSynchronize(ctx->stream);
+                fprintf(stderr, "[pylda debug] class %d live-topic kernel: %s\n", slot, hipGetErrorString(e));
+            }
             close_bracket(class_bracket, ctx->stream);
             if (rc != PYLDA_OK) {
                 join();
@@ -320,6 +354,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             }
         }
         ctx->stream = main_stream;
+        p.handoff_live = 0;
         if (uber_from >= 0) {
             const Launch& L = c->plan[(size_t)uber_from];
             p.order = c->d_order + L.first;
@@ -363,7 +398,8 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     close_bracket(doc_bracket, ctx->stream);
     if (ctx->profiling) ctx->estep_calls += 1;
     if (ctx->profiling && c->D > 0)       // inner iterations actually executed, for the fp64 roofline and doc-iterations/s
-        hipLaunchKernelGGL(work_count_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_iters, c->d_doc_ptr, c->D, ctx->d_work);
+        hipLaunchKernelGGL(work_count_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_iters, c->d_doc_ptr, c->D, ctx->d_work,
+                           c->compact_ready ? c->d_handoff_it : nullptr, c->d_col_iters, K);
 
     // sufficient statistics (:207): gather pass over the postings, no atomics
     if (!heldout) {

@@ -41,7 +41,18 @@ struct EstepParams {
     int n_cap;                // max distinct terms of any document in this launch
     int tile_stride;          // LDS row stride in doubles (odd)
     double* term_scratch;     // nnz scratch doubles, only for documents too long for the LDS (estep_generic.h MODE 2)
+    // ---- hand-over to the live-topic kernel (estep_compact.h); handoff_live == 0: never ----
+    int handoff_live;         // a document leaves the dense kernel once at most this many topics have gamma_k != alpha_k
+    int32_t* live_n;          // D out: live topics of a document handed over (status 4)
+    uint16_t* live_idx;       // D x kLiveStride out: their indices, ascending
+    double* live_tile;        // the document's compact tile: value of term n, live topic j at live_tile[tile_ptr[d] + j * N_d + n]
+    const int64_t* tile_ptr;  // D offsets into live_tile (doubles)
+    double alpha_max, alpha_min;   // over the K topics (the exactness guard of the live-topic kernel)
+    int32_t* handoff_it;      // D out: inner iterations the dense kernel ran before it handed the document over (else left at -1)
+    int32_t* col_iters;       // D out: sum over the live-topic kernel's iterations of the tile columns it ran them on
 };
+
+constexpr int kLiveStride = 32;   // entries per document in live_idx: the largest live set the live-topic kernel takes over
 
 // Sum over the 64 lanes, result in every lane, without the LDS crossbar (ds_bpermute costs an LDS
 // round trip per level): four DPP levels inside each 16-lane row, then one permlane16 and one
@@ -377,28 +388,36 @@ __device__ __forceinline__ void lds_row_wait(LdsRow& r)
 // registers) plus a 32-bit byte offset per lane - one VGPR per row instead of a pointer pair, in kernels at the
 // register limit; the host only selects these kernels while the table is below 4 GiB.  The wait is vmcnt(0): the
 // loops that use it keep one such row in flight per wavefront, and any older load of the thread has landed by then.
+// The s_nop: a VMEM instruction needs five wait states behind a VALU write of its scalar base, and the compiler's
+// hazard recogniser does not look inside the asm - when the base had been spilled to a vector register's lanes, its
+// v_readlane reload sat right in front of the load (found as a memory fault of the streamed classes in round 6).
 template <int PIECE>
 __device__ __forceinline__ void table_row_request(LdsRow& r, const void* base, unsigned byte_offset)
 {
     static_assert(PIECE == 128 || PIECE == 256 || PIECE == 512, "8, 16 or 32 topic lanes");
     if constexpr (PIECE == 128)
-        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:128\n\t"
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:128\n\t"
                      "global_load_dwordx4 %2, %4, %5 offset:256\n\tglobal_load_dwordx4 %3, %4, %5 offset:384"
                      : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
                      : "v"(byte_offset), "s"(base)
                      : "memory");
     else if constexpr (PIECE == 256)
-        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:256\n\t"
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:256\n\t"
                      "global_load_dwordx4 %2, %4, %5 offset:512\n\tglobal_load_dwordx4 %3, %4, %5 offset:768"
                      : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
                      : "v"(byte_offset), "s"(base)
                      : "memory");
     else
-        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:512\n\t"
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:512\n\t"
                      "global_load_dwordx4 %2, %4, %5 offset:1024\n\tglobal_load_dwordx4 %3, %4, %5 offset:1536"
                      : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]), "=&v"(r.p[3])
                      : "v"(byte_offset), "s"(base)
                      : "memory");
+}
+// one double to uniform base + 32-bit byte offset (the store's address is ONE vector register)
+__device__ __forceinline__ void store_f64_uniform_base(double* base, unsigned byte_offset, double v)
+{
+    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" : : "v"(byte_offset), "v"(v), "s"(base) : "memory");
 }
 __device__ __forceinline__ void table_row_wait(LdsRow& r)
 {

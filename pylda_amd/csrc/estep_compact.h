@@ -1,0 +1,489 @@
+// Live-topic E-step kernel: the inner loop of variational_bayes.py:174-190 on the topics of a document that still move.
+//
+// Why.  With alpha_k ~ 1/K a topic the document does not use decays super-exponentially (exp(psi(gamma)) ~ exp(-1/gamma)):
+// after a handful of iterations  gamma'_k = fma(t_k, S_k, alpha_k)  rounds to alpha_k BITWISE, and from then on
+// t_k = exp(psi(alpha_k) - psi(sum gamma)) ~ 1e-114 (K = 256) is a constant that adds less than 2^-60 relative to any
+// normaliser and nothing to its own gamma: the topic is dead, exactly.  Measured inside the bench's timed window
+// (tools/live_probe.py, cfg 4): 256 live topics through iteration 4, 141 at 6, 58 at 8, 33 at 10, 23 at 12, 16 at 15,
+// 9 at 30, 7 at 50 - nine tenths of the dense N x K tile a document kernel streams through the fp64 pipes 50 times are
+// columns that cannot change a bit of the result.  The dense kernels (estep_quad.h) therefore hand a document over
+// once at most `handoff_live` topics are alive: gamma, the live topics' indices and their columns of the tile.
+//
+// Here ONE wavefront runs the remaining iterations of a document on its N x L tile, eight documents per CU (the dense
+// kernel at K = 256: one):
+//   * a lane owns terms n = lane + 64 s, s < S, with their L tile values in registers: the normalisers are lane-local
+//     FMAs with t_j as a SCALAR operand (no cross-lane step at all in the pass that has N outputs);
+//   * the topic sums q_j = sum_n r_n C[n][j] are L values reduced over the 64 lanes by a reduce-scatter - each of the six
+//     exchange levels halves the values a lane carries (permlane32/16 swaps, then DPP inside the 16-lane rows) - after
+//     which lane l owns column j(l): gamma update, exp(psi(gamma) - psi(sum gamma)), |delta gamma| on L lanes at once;
+//   * t_j goes back to scalar registers by v_readlane; no LDS, no barrier inside the loop.
+// When the live set has shrunk to the next smaller instantiation the wavefront reloads the surviving columns (an L2 hit:
+// it wrote or read them microseconds ago) and goes on with fewer.
+//
+// Exactness.  Same arithmetic as the dense kernels on the live topics (the same exp_digamma_minus_levels, the same
+// 2^-40 fixed-point stop sum - a dead topic's |delta gamma| is exactly 0), another summation ORDER inside normalisers and
+// topic sums: results differ from the dense kernel's by rounding (<= a few ulp), from the oracle by the same 1e-13 as
+// before.  What is dropped - the dead topics' B t ~ 1e-114 in the normalisers - is guarded per document from live
+// quantities only: with t_dead = exp(psi(alpha_max) - psi(sum gamma)) >= every dead topic's t,
+//     K t_dead             <  2^-60 min_n normaliser_n      (a normaliser moves by < 2^-60 relative)
+//     t_dead N max_n r_n   <  2^-54 alpha_min               (fma(t_k, S_k, alpha_k) still rounds to alpha_k: dead stays dead)
+// over ALL iterations run here; a document that fails either is flagged (status 1) and redone by the log-space kernel,
+// the reference's own formulation - like a document whose normaliser leaves the fp64 range.
+#pragma once
+#include "estep_common.h"
+#include "special_device.h"
+
+namespace pylda {
+
+// ---- the reduce-scatter over the 64 lanes --------------------------------------------------------------------------
+// Level k exchanges between lanes that differ in bit 5 - k.  Of R values a lane keeps ceil(R / 2): the lanes with the
+// bit clear the first half, the others the second (index + half; beyond R: padding, carried as zero); R == 1: both keep
+// the sum (replicas).  After six levels one value is left: lane l holds column sum_k bit_k(l) half_k.
+constexpr int compact_half(int r) { return (r + 1) / 2; }
+constexpr int compact_count_at(int lt, int level)       // values per lane entering `level`
+{
+    int r = lt;
+    for (int k = 0; k < level; ++k) r = r > 1 ? compact_half(r) : 1;
+    return r;
+}
+// column of lane `lane`, or -1 (padding); `primary`: the replica with the lowest lane number
+constexpr int compact_column_of(int lt, int lane, bool* primary)
+{
+    int m = 0;
+    bool valid = true, first = true;
+    for (int k = 5; k >= 0; --k) {                      // from the last level back to the first
+        const int r = compact_count_at(lt, k), bit = (lane >> (5 - k)) & 1;
+        if (r == 1) {
+            if (bit) first = false;
+            continue;
+        }
+        const int half = compact_half(r);
+        if (bit) {
+            m += half;
+            if (m >= r) valid = false;
+        }
+    }
+    if (primary) *primary = valid && first;
+    return valid ? m : -1;
+}
+constexpr int compact_lane_of(int lt, int column)
+{
+    for (int lane = 0; lane < 64; ++lane) {
+        bool primary = false;
+        if (compact_column_of(lt, lane, &primary) == column && primary) return lane;
+    }
+    return -1;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double compact_dpp_add(double keep, double send) { return keep + dpp_f64<CTRL>(send); }
+
+// one level: x[0 .. R) -> y[0 .. ceil(R / 2))
+template <int LEVEL, int R>
+__device__ __forceinline__ void compact_level(const double (&x)[R], double (&y)[(R + 1) / 2 > 0 ? (R + 1) / 2 : 1], bool upper)
+{
+    constexpr int H = (R + 1) / 2;
+    if constexpr (R == 1) {
+        if constexpr (LEVEL == 0) y[0] = swap32_add(x[0], x[0]);
+        else if constexpr (LEVEL == 1) y[0] = swap16_add(x[0], x[0]);
+        else if constexpr (LEVEL == 2) y[0] = compact_dpp_add<0x140>(x[0], x[0]);       // row_mirror
+        else if constexpr (LEVEL == 3) y[0] = compact_dpp_add<0x141>(x[0], x[0]);       // row_half_mirror
+        else if constexpr (LEVEL == 4) y[0] = compact_dpp_add<0x4E>(x[0], x[0]);        // quad_perm [2,3,0,1]
+        else y[0] = compact_dpp_add<0xB1>(x[0], x[0]);                                  // quad_perm [1,0,3,2]
+    } else {
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+            const double a = x[m], b = m + H < R ? x[m + H < R ? m + H : 0] : 0.0;
+            if constexpr (LEVEL == 0) y[m] = swap32_add(a, b);
+            else if constexpr (LEVEL == 1) y[m] = swap16_add(a, b);
+            else {
+                const double keep = upper ? b : a, send = upper ? a : b;
+                if constexpr (LEVEL == 2) y[m] = compact_dpp_add<0x140>(keep, send);
+                else if constexpr (LEVEL == 3) y[m] = compact_dpp_add<0x141>(keep, send);
+                else if constexpr (LEVEL == 4) y[m] = compact_dpp_add<0x4E>(keep, send);
+                else y[m] = compact_dpp_add<0xB1>(keep, send);
+            }
+        }
+    }
+}
+
+// levels LEVEL .. 5 on x[0 .. R): the one value left
+template <int LEVEL, int R>
+__device__ __forceinline__ double compact_reduce_from(const double (&x)[R], int lane)
+{
+    double y[(R + 1) / 2 > 0 ? (R + 1) / 2 : 1];
+    compact_level<LEVEL, R>(x, y, ((lane >> (5 - LEVEL)) & 1) != 0);
+    if constexpr (LEVEL == 5) {
+        static_assert(R <= 2, "six levels reduce at most 64 values");
+        return y[0];
+    } else {
+        return compact_reduce_from<LEVEL + 1, (R + 1) / 2>(y, lane);
+    }
+}
+
+// ---- LDS of a wavefront: the hand-over state between bodies, and the epilogue's row of t ----
+struct CompactLds {
+    double gam[kLiveStride];        // gamma of the live topics (column order)
+    double gprev[kLiveStride];      // ... before the last update
+    double tlast[kLiveStride];      // t of the last executed iteration
+    double alf[kLiveStride];        // alpha of the live topics
+    int idx[kLiveStride];           // topic of column j
+    int col[kLiveStride];           // its column in the document's tile in memory
+    unsigned member[32];            // bit k: topic k is a column (K <= 1024)
+};
+
+struct CompactState {
+    int L;                  // live columns
+    int it, left;           // iterations executed / left
+    int cols;               // sum over the iterations run here of the tile columns they ran on (work counter)
+    int bad;                // a normaliser left the fp64 range, or the exactness guard failed
+    double nrm_min, r_max;  // over the iterations run here (per lane; reduced at the end)
+};
+
+enum CompactExit { kCompactDone = 0, kCompactShrink = 1 };
+
+// The inner loop on an S x LT register tile.  Returns when the document is finished (stop test, iteration cap) or when
+// at most `shrink_to` columns are still alive (0: never) - st.L, lds.idx / col / gam are then the surviving ones.
+template <int S, int LT>
+__device__ __forceinline__ int compact_body(const EstepParams& p, int doc, int64_t lo, int N, double psi_total, double thresh_f,
+                                            CompactLds& lds, CompactState& st, int shrink_to, double (&r)[S])
+{
+    static_assert(LT >= 4 && LT <= kLiveStride && LT % 4 == 0, "columns of the register tile");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int L = st.L;
+    const double* tile = p.live_tile + p.tile_ptr[doc];
+
+    // the tile: C[s][j] = value of term lane + 64 s, column j.  A term slot beyond the document: ones (its normaliser is
+    // sum_j t_j > 0, its count 0); a column beyond L: zeros (t_j = 0 as well)
+    double C[S][LT];
+    double cnt[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int n = s * kWave + lane;
+        cnt[s] = n < N ? (double)p.term_ct[lo + n] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < LT; ++j) {
+        const int cj = __builtin_amdgcn_readfirstlane(j < L ? lds.col[j < kLiveStride ? j : 0] : 0);
+        const double* column = tile + (size_t)cj * N;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int n = s * kWave + lane;
+            C[s][j] = j < L ? (n < N ? column[n] : 1.0) : 0.0;
+        }
+    }
+
+    // this lane's column in the gamma phase (the recursion of compact_column_of on the lane's bits, shape constants folded)
+    bool primary = false;
+    int mycol = -1;
+    {
+        int m = 0;
+        bool valid = true, first = true;
+        static_for<6>([&](auto idx) {
+            constexpr int k = 5 - decltype(idx)::value;
+            constexpr int rr = compact_count_at(LT, k), half = compact_half(rr);
+            const bool bit = ((lane >> (5 - k)) & 1) != 0;
+            if constexpr (rr == 1) {
+                if (bit) first = false;
+            } else {
+                if (bit) {
+                    m += half;
+                    if (m >= rr) valid = false;
+                }
+            }
+        });
+        mycol = valid && m < L ? m : -1;
+        primary = mycol >= 0 && first;
+    }
+    const bool owns = mycol >= 0;
+    double gam = owns ? lds.gam[owns ? mycol : 0] : 1.0;
+    const double alpha_k = owns ? lds.alf[owns ? mycol : 0] : 1.0;
+    double t;
+    {
+        ExpDigammaLevelsA coef_a;
+        coef_a.load();
+        t = exp_digamma_minus_levels(gam, psi_total, coef_a);
+        if (!owns) t = 0.0;
+    }
+    double gprev = gam, tused = t;
+    int it = st.it, left = st.left, bad = st.bad;
+    double nrm_min = st.nrm_min, r_max = st.r_max;
+    int exit_code = kCompactDone;
+
+    for (;;) {                                                                // :174
+        // t_j as scalars
+        double ts[LT];
+        static_for<LT>([&](auto idx) {
+            constexpr int j = decltype(idx)::value;
+            constexpr int from = compact_lane_of(LT, j);
+            static_assert(from >= 0 && from < kWave, "every column has a lane");
+            ts[j] = readlane_f64(t, from);
+        });
+        tused = t;
+        // A. normalisers, lane-local                                            :177-182
+        double nrm[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) nrm[s] = C[s][0] * ts[0];
+#pragma unroll
+        for (int j = 1; j < LT; ++j)
+#pragma unroll
+            for (int s = 0; s < S; ++s) nrm[s] = fma(C[s][j], ts[j], nrm[s]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (cnt[s] > 0.0 && !(nrm[s] > 1e-280)) bad = 1;
+            r[s] = cnt[s] * rcp_newton(nrm[s]);
+            nrm_min = fmin(nrm_min, nrm[s]);
+            r_max = fmax(r_max, r[s]);
+        }
+        // both coefficient tables of exp_digamma_minus_levels (62 scalar registers) are fetched again in every iteration,
+        // here, where the t_j have just been used for the last time: resident they would push the t_j out of the scalar file
+        ExpDigammaLevelsA coef_a;
+        ExpDigammaLevelsB coef_b;
+        coef_a.load();
+        coef_b.load();
+        // B. topic sums: per lane over its terms, then over the lanes                 :185
+        constexpr int H0 = (LT + 1) / 2;
+        double y0[H0];
+#pragma unroll
+        for (int m = 0; m < H0; ++m) {
+            double qa = r[0] * C[0][m], qb = m + H0 < LT ? r[0] * C[0][m + H0 < LT ? m + H0 : 0] : 0.0;
+#pragma unroll
+            for (int s = 1; s < S; ++s) {
+                qa = fma(r[s], C[s][m], qa);
+                if (m + H0 < LT) qb = fma(r[s], C[s][m + H0 < LT ? m + H0 : 0], qb);
+            }
+            y0[m] = swap32_add(qa, qb);
+        }
+        const double q = compact_reduce_from<1, H0>(y0, lane);
+        // C. gamma update on the lanes that own a column                               :185-188
+        const double gnew = fma(t, q, alpha_k);
+        const double diff = fabs(gnew - gam);
+        gprev = gam;
+        gam = gnew;
+        double moved = primary ? __builtin_rint(fmin(diff, 1024.0) * kChangeScale) : 0.0;
+        t = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
+        if (!owns) t = 0.0;
+        // the stop sum in 2^-40 fixed point, as the dense kernels form it (integers in doubles: exact below 2^53, and
+        // a sum that is not exact is far above any threshold of the fixed-point range)
+        moved = wave_sum(moved);
+        ++it;
+        --left;
+        if (moved <= thresh_f || left <= 0) break;                            // :189, :174
+        if (shrink_to > 0) {
+            const int alive = __builtin_popcountll(__ballot(primary && gam != alpha_k));
+            if (alive <= shrink_to) {
+                exit_code = kCompactShrink;
+                break;
+            }
+        }
+    }
+
+    // state back to LDS: gamma, the gamma before the last update and the t used last, per column
+    if (primary) {
+        lds.gam[mycol] = gam;
+        lds.gprev[mycol] = gprev;
+        lds.tlast[mycol] = tused;
+    }
+    wave_lds_exchange();
+    if (exit_code == kCompactShrink) {
+        // the columns still alive move up, in order: lane j < L looks after column j
+        const bool mine = lane < L;
+        const int at = mine ? lane : 0;
+        const double g = lds.gam[at], a = lds.alf[at];
+        const int topic = lds.idx[at], column = lds.col[at];
+        const bool alive = mine && g != a;
+        const unsigned long long mask = __ballot(alive);
+        // a column that died here: its gamma is alpha_k for good
+        if (mine && !alive) p.gamma[(size_t)doc * p.K + topic] = g;
+        wave_lds_exchange();
+        if (alive) {
+            const int to = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            lds.gam[to] = g;
+            lds.alf[to] = a;
+            lds.idx[to] = topic;
+            lds.col[to] = column;
+        }
+        wave_lds_exchange();
+        st.L = __builtin_popcountll(mask);
+    }
+    st.cols += (it - st.it) * LT;
+    st.it = it;
+    st.left = left;
+    st.bad = bad;
+    st.nrm_min = nrm_min;
+    st.r_max = r_max;
+    return exit_code;
+}
+
+__device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
+
+constexpr size_t compact_lds_bytes(int ldk) { return ((sizeof(CompactLds) + 15) & ~(size_t)15) + (size_t)ldk * 8; }
+
+// One wavefront per document of the launch class; S = term slots per lane (N <= 64 S).  Documents the dense kernel
+// finished itself (status != 4) are skipped.
+template <int S, int LTMAX>
+__global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CompactLds& lds = *reinterpret_cast<CompactLds*>(smem);
+    double* trow = reinterpret_cast<double*>(smem + ((sizeof(CompactLds) + 15) & ~(size_t)15));     // [ldk]
+    const int lane = threadIdx.x;
+    const int doc = p.order[blockIdx.x];
+    if (p.status[doc] != 4) return;
+    const int K = p.K, ldk = p.ldk;
+    const int64_t lo = p.doc_ptr[doc];
+    const int N = (int)(p.doc_ptr[doc + 1] - lo);
+    const int L0 = p.live_n[doc];
+
+    if (lane < L0) {
+        const int topic = p.live_idx[(size_t)doc * kLiveStride + lane];
+        lds.idx[lane] = topic;
+        lds.col[lane] = lane;
+        lds.gam[lane] = p.gamma[(size_t)doc * K + topic];
+        lds.alf[lane] = p.alpha[topic];
+    }
+    // total token count (:162) and psi(sum_k gamma_k), formed as the dense kernels form them (the same bits)
+    double local = 0.0;
+    for (int n = lane; n < N; n += kWave) local += (double)p.term_ct[lo + n];
+    double asum = 0.0;
+    for (int k = lane; k < K; k += kWave) asum += p.alpha[k];
+    const double total = wave_sum(local);
+    asum = wave_sum(asum);
+    const double psi_total = uniform_f64(digamma(asum + total));
+    const double thresh_f = p.tol * K * kChangeScale;
+    wave_lds_exchange();
+
+    CompactState st;
+    st.L = L0;
+    st.it = p.iters[doc];
+    st.left = p.max_iter - st.it;
+    st.cols = 0;
+    st.bad = 0;
+    st.nrm_min = 1e300;
+    st.r_max = 0.0;
+    double r[S];
+    for (;;) {
+        int code;
+        // the smallest instantiation that holds the live columns; it runs until the next smaller one would do
+        if constexpr (LTMAX > 24) {
+            if (st.L > 24) {
+                code = compact_body<S, LTMAX>(p, doc, lo, N, psi_total, thresh_f, lds, st, 24, r);
+                if (code == kCompactDone) break;
+                continue;
+            }
+        }
+        if constexpr (LTMAX > 16) {
+            if (st.L > 16) {
+                code = compact_body<S, (LTMAX < 24 ? LTMAX : 24)>(p, doc, lo, N, psi_total, thresh_f, lds, st, 16, r);
+                if (code == kCompactDone) break;
+                continue;
+            }
+        }
+        if (st.L > 8) {
+            code = compact_body<S, 16>(p, doc, lo, N, psi_total, thresh_f, lds, st, 8, r);
+            if (code == kCompactDone) break;
+            continue;
+        }
+        code = compact_body<S, 8>(p, doc, lo, N, psi_total, thresh_f, lds, st, 0, r);
+        break;
+    }
+    const int L = st.L;
+
+    // ---- the exactness guard (header), from the extremes over every iteration run here ----
+    {
+        const double nrm_min = wave_min(st.nrm_min), r_max = wave_max(st.r_max);
+        const double t_dead = exp_digamma_minus(p.alpha_max, psi_total);
+        const bool safe = (double)K * t_dead < 8.673617379884035e-19 * nrm_min &&            // 2^-60
+                          t_dead * (double)N * r_max < 5.551115123125783e-17 * p.alpha_min;     // 2^-54
+        if (!safe) st.bad = 1;
+    }
+    if (__ballot(st.bad != 0) != 0ull) {
+        if (!p.heldout) {      // contributes nothing to the gather pass; the log-space kernel adds it
+            for (int n = lane; n < N; n += kWave) p.rfinal[lo + n] = 0.0;
+            for (int k = lane; k < ldk; k += kWave) p.tfinal[(size_t)doc * ldk + k] = 0.0;
+        }
+        if (lane == 0) p.status[doc] = 1;
+        return;
+    }
+
+    // the row of t for the statistics pass: t of the last executed iteration at the live topics, 0 elsewhere (a dead
+    // topic's 1e-114 is below the last bit of every statistic it would touch: eta = statistics + beta is unchanged)
+    const bool mine = lane < L;
+    const int at = mine ? lane : 0;
+    const int topic = lds.idx[at];
+    const double gam = lds.gam[at], gprev = lds.gprev[at], tlast = lds.tlast[at], alpha_k = lds.alf[at];
+    if (mine) p.gamma[(size_t)doc * K + topic] = gam;
+    if (lane == 0) p.col_iters[doc] = st.cols;
+    if (!p.heldout) {
+        for (int k = lane; k < ldk; k += kWave) trow[k] = 0.0;
+        wave_lds_exchange();
+        if (mine) trow[topic] = tlast;
+        wave_lds_exchange();
+        for (int k = lane; k < ldk; k += kWave) p.tfinal[(size_t)doc * ldk + k] = trow[k];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int n = s * kWave + lane;
+            if (n < N) p.rfinal[lo + n] = r[s];
+        }
+    }
+    // ---- training fast path: the document terms are left to doc_terms_kernel (doc_terms.h) ----
+    if (!p.heldout && !p.want_doc_ll) {
+        if (lane == 0) {
+            p.iters[doc] = st.it;
+            p.status[doc] = 3;
+        }
+        return;
+    }
+
+    // ---- document terms (:195-204) with the last phi = B t r, as the dense kernels' epilogue (estep_epilogue.h) ----
+    if (lane < 32) lds.member[lane] = 0u;
+    wave_lds_exchange();
+    if (mine) atomicOr(&lds.member[topic >> 5], 1u << (topic & 31));
+    wave_lds_exchange();
+    double term1 = 0.0, term3 = 0.0, shift_term = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int n = s * kWave + lane;
+        if (n < N) {
+            const int w = p.term_id[lo + n];
+            const double* row = p.expElog_elog + (size_t)w * ldk;
+            double gsum = 0.0;
+            for (int j = 0; j < L; ++j) gsum = fma(row[lds.idx[j]], lds.tlast[j], gsum);
+            term1 = fma(r[s], gsum, term1);
+            const double c = (double)p.term_ct[lo + n];
+            term3 = fma(c, log(c) - log(r[s]), term3);                    // c_n log(normaliser_n)
+            if (p.heldout) shift_term = fma(c, p.shift[w], shift_term);
+        }
+    }
+    double term2 = 0.0, lse_term = 0.0, lgam = 0.0, gsum_all = 0.0;
+    if (mine) {
+        const double mass = gam - alpha_k;                                // = t_last * sum_n r_n B[w_n][k]
+        term2 = (digamma(gprev) - psi_total) * mass;
+        if (p.heldout) lse_term = p.topic_lse[topic] * mass;
+        lgam = lgamma_pos(gam);
+        gsum_all = gam;
+    }
+    for (int k = lane; k < K; k += kWave) {                               // the topics that are not columns sit at alpha_k
+        if (!((lds.member[k >> 5] >> (k & 31)) & 1u)) {
+            const double a = p.alpha[k];
+            lgam += lgamma_pos(a);
+            gsum_all += a;
+        }
+    }
+    term1 = wave_sum(term1);
+    term2 = wave_sum(term2);
+    term3 = wave_sum(term3);
+    shift_term = wave_sum(shift_term);
+    lse_term = wave_sum(lse_term);
+    lgam = wave_sum(lgam);
+    gsum_all = wave_sum(gsum_all);
+    if (lane == 0) {
+        const double ent = term1 + term2 - term3;
+        p.doc_ll[doc] = p.alpha_term + lgam - lgamma_pos(gsum_all) - ent;        // :195-199
+        p.doc_words_ll[doc] = p.heldout ? term1 + shift_term - lse_term : 0.0;   // :204
+        p.iters[doc] = st.it;
+        p.status[doc] = 0;
+    }
+}
+
+}  // namespace pylda

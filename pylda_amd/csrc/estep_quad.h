@@ -58,7 +58,8 @@ struct QuadLds {
     static constexpr size_t red = 0;                                               // [W][G][8][kRedStride]; reused for the W x kTopics partial sums
     static constexpr size_t tt = red + (size_t)W * red_wave;                       // [2][kTopics]
     static constexpr size_t chg = tt + (size_t)2 * kTopics * 8;                    // u64[2]
-    static constexpr size_t misc = chg + 16;                                       // [8][W]
+    static constexpr size_t livec = chg + 16;                                      // u32[2] (+ 8 bytes of padding): topics with gamma_k != alpha_k
+    static constexpr size_t misc = livec + 16;                                     // [8][W]
     static constexpr size_t alf = misc + (size_t)8 * W * 8;                        // [kTopics] alpha (1 beyond K)
     static constexpr size_t gpv = alf + (size_t)kTopics * 8;                       // [kTopics] gamma before the last update
     static constexpr size_t cnt = gpv + (size_t)kTopics * 8;                       // double [2][W * 64] counts of the words a lane finishes
@@ -74,6 +75,77 @@ constexpr int quad_stream_stop(int swl, int stop)
 {
     return swl == 4 ? stop : swl == 3 ? (stop == 0 ? 0 : stop == 2 ? 1 : stop == 3 ? 2 : -1)
          : swl == 2 ? (stop == 0 ? 0 : stop == 3 ? 1 : -1) : swl == 1 ? (stop == 0 ? 0 : -1) : -1;
+}
+
+// Hand-over of a document to the live-topic kernel (estep_compact.h), which runs the remaining iterations on the
+// document's N x L tile - one wavefront, eight documents per CU.  What it needs: gamma after `it` updates (a dead topic
+// stays at alpha_k), the live topics in ascending order, and their columns of the tile, term-minor (its lanes own terms).
+// Everything lane-shaped is formed again from the thread index: nothing of the prologue is kept alive for this exit.
+template <int TL, int RWL, int TWL, int SWL>
+__device__ __forceinline__ void quad_hand_over(const EstepParams& p, char* smem, const double (&B)[RWL][8], double gam, int doc, int64_t lo, int N,
+                                               int it)
+{
+    using L = QuadLds<TL, RWL, TWL>;
+    constexpr int G = L::G, KT = 8 * TL, KRL = 8, WPR = RWL + TWL, WPG = WPR + SWL;
+    const int K = p.K;
+    double* tt = reinterpret_cast<double*>(smem + L::tt);
+    double* misc = reinterpret_cast<double*>(smem + L::misc);
+    const double* alf = reinterpret_cast<const double*>(smem + L::alf);
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int c = lane % TL, gg = wave * G + lane / TL;
+    const int trank = wave < KT / kWave ? wave : -1;
+    const int ktid = trank >= 0 ? trank * kWave + lane : 0;
+    int* pos = reinterpret_cast<int*>(tt);                                // [KT]: column of topic k in the compact tile, or -1
+    unsigned* wcount = reinterpret_cast<unsigned*>(misc);                 // live topics per topic wavefront
+    const bool alive = trank >= 0 && ktid < K && gam != alf[ktid];
+    const unsigned long long mask = __ballot(alive);
+    if (trank >= 0 && lane == 0) wcount[trank] = (unsigned)__builtin_popcountll(mask);
+    __syncthreads();                                                      // (every read of tt[] by the loop is behind us: __syncthreads_or)
+    if (trank >= 0) {
+        int at = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        for (int w = 0; w < trank; ++w) at += (int)wcount[w];
+        pos[ktid] = alive ? at : -1;
+        if (alive) p.live_idx[(size_t)doc * kLiveStride + at] = (uint16_t)ktid;
+        if (ktid < K) p.gamma[(size_t)doc * K + ktid] = gam;
+    }
+    __syncthreads();
+    // uniform base + 32-bit byte offset: one address register per store instead of a pointer pair (a document's tile is
+    // at most 256 x 32 x 8 bytes)
+    double* tile = p.live_tile + p.tile_ptr[doc];
+    {
+        unsigned long long bits = reinterpret_cast<unsigned long long>(tile);
+        bits = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bits);
+        tile = reinterpret_cast<double*>(bits);
+    }
+    const double2* rows = reinterpret_cast<const double2*>(smem + L::rows) + (size_t)gg * TWL * (KT / 2) + c;
+    // topic by topic of this lane's eight (2 c + 2 TL jj + {0, 1}): its column, then the lane's terms
+    static_for<KRL>([&](auto idx) {
+        constexpr int j = decltype(idx)::value;
+        const int at = pos[2 * (c + TL * (j / 2)) + (j & 1)];
+        if (at >= 0) {
+            const unsigned base = (unsigned)(at * N) * 8u;
+#pragma unroll
+            for (int s = 0; s < WPG; ++s) {
+                const int n = s * 16 + (s < WPR ? gg : 15 - gg);
+                if (n < N) {
+                    double v;
+                    if (s < RWL) v = B[s < RWL ? s : 0][j];
+                    else if (s < WPR) v = reinterpret_cast<const double*>(rows + (s - RWL) * (KT / 2) + TL * (j / 2))[j & 1];
+                    else v = p.expElog[(size_t)p.term_id[lo + n] * p.ldk + 2 * (c + TL * (j / 2)) + (j & 1)];
+                    store_f64_uniform_base(tile, base + (unsigned)n * 8u, v);
+                }
+            }
+        }
+    });
+    if (tid == 0) {
+        unsigned total_live = 0;
+        for (int w = 0; w < KT / kWave; ++w) total_live += wcount[w];
+        p.live_n[doc] = (int)total_live;
+        p.handoff_it[doc] = it;
+        p.iters[doc] = it;
+        p.status[doc] = 4;
+    }
 }
 
 // SWL > 0: word slots beyond the register and LDS capacity - documents of 225-256 terms at stride 256, the 3 % of cfg 4
@@ -118,6 +190,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     double* red = reinterpret_cast<double*>(smem + L::red);
     double* tt = reinterpret_cast<double*>(smem + L::tt);
     unsigned long long* chg = reinterpret_cast<unsigned long long*>(smem + L::chg);
+    unsigned* livec = reinterpret_cast<unsigned*>(smem + L::livec);
     double* misc = reinterpret_cast<double*>(smem + L::misc);
     double* alf = reinterpret_cast<double*>(smem + L::alf);
     double* gpv = reinterpret_cast<double*>(smem + L::gpv);
@@ -236,7 +309,10 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     local = wave_sum(local);
     asum = wave_sum(asum);
     if (lane == 0) misc[wave] = local;
-    if (tid == 0) chg[0] = chg[1] = 0ull;
+    if (tid == 0) {
+        chg[0] = chg[1] = 0ull;
+        livec[0] = livec[1] = 0u;
+    }
     lds_only_barrier();
     // the gamma phase: one thread per topic on the first KT / 64 wavefronts.  (Measured and not adopted: taking
     // the two documents' gamma wavefronts on disjoint SIMD pairs - HW_ID / LDS_ALLOC tell a workgroup where it
@@ -280,6 +356,10 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         !(thresh_f >= 0.0) ? -1ll : thresh_f >= 9.2e18 ? 0x7fffffffffffffffll : (long long)thresh_f)));
     long long moved = 0x7fffffffffffffffll;
     int left = p.max_iter;
+    // topics whose gamma differs from alpha (bitwise) after the last update, and the count at which the document
+    // leaves this kernel (-1: never)
+    int nlive = KT;
+    const int handoff_at = p.handoff_live > 0 ? p.handoff_live : -1;
     double tq[KRL];
 #pragma unroll
     for (int jj = 0; jj < KRL / 2; ++jj) {
@@ -353,9 +433,17 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         }
 #pragma unroll
         for (int i = 0; i < C0; ++i) myred[i * RS + cw] = PRE ? lane_group_sum<2>(a[i]) : a[i];
-        if (moved <= thresh || left <= 0) {                               // :189 (mean <= tol), :174
+        // ... or the document is handed to the live-topic kernel (estep_compact.h): few enough topics still move
+        const bool done = moved <= thresh || left <= 0;                   // :189 (mean <= tol), :174
+        if (done || nlive <= handoff_at) {
             if constexpr (TWL > 2) lds_row_wait(rowbuf);                  // no read may land after the loop (row 2 is in flight)
             if constexpr (SWL > 1) table_row_wait(sbuf);
+            // (the hand-over sits INSIDE the loop, where the tile is alive anyway: behind the loop it would stretch the
+            //  tile's live range over the exit paths and the allocator answers by spilling two tile rows in the loop)
+            if (!done && !__syncthreads_or(bad)) {
+                quad_hand_over<TL, RWL, TWL, SWL>(p, smem, B, gam, doc, lo, N, it);
+                return;
+            }
             break;
         }
         wave_lds_exchange();
@@ -507,14 +595,31 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             gpv[ktid] = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
+            {   // (a padding topic has alpha = gamma = 1 and t = 0: never counted)
+                const unsigned long long moving = __ballot(gnew != alpha_k);
+                if (lane == 0) atomicAdd(&livec[buf], (unsigned)__builtin_popcountll(moving));
+            }
             const double t_next = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
             tt[(buf ^ 1) * KT + ktid] = topic_live ? t_next : 0.0;
-            if (ktid == 0) store_u64_hi(&chg[buf ^ 1], 0u);
+            if (ktid == 0) {
+                store_u64_hi(&chg[buf ^ 1], 0u);
+                livec[buf ^ 1] = 0u;
+            }
         }
         ++it;
         --left;
         __syncthreads();
-        moved = (long long)chg[buf];
+        // (both uniform.  The live count always sits in a scalar register; the stop sum where that frees a vector register
+        //  pair the allocator can use - these kernels sit AT the 256-register limit and the allocation is chaotic around
+        //  it: tools/kernel_resources.py "HOT BLOCK" lines, checked by tests/test_kernel_resources.py)
+        if constexpr (TL == 32) {
+            const unsigned long long m = chg[buf];
+            moved = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)m));
+        } else {
+            moved = (long long)chg[buf];
+        }
+        nlive = __builtin_amdgcn_readfirstlane((int)livec[buf]);
 #pragma unroll
         for (int jj = 0; jj < KRL / 2; ++jj) {
             const double2 t2 = reinterpret_cast<const double2*>(tt + (buf ^ 1) * KT)[c + TL * jj];

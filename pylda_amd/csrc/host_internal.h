@@ -87,7 +87,9 @@ struct pylda_ctx {
     NewtonParams newton;
     double* d_newton_work = nullptr;   // 4 K
     double* d_eta_ckpt = nullptr;   // pylda_model_checkpoint
-    double* d_work = nullptr;       // profiling: [sum_d I_d, sum_d I_d N_d] accumulated over E-steps
+    double* d_work = nullptr;       // profiling: [sum_d I_d, sum_d I_d N_d, tile entries executed, documents handed over] accumulated over E-steps
+    double work_cache[4] = {0.0, 0.0, 0.0, 0.0};   // one read of d_work serves pylda_work_counters and pylda_executed_work
+    bool work_cached = false;
     hipEvent_t mark_event[4] = {nullptr, nullptr, nullptr, nullptr};
     void* comm = nullptr;           // RCCL communicator of pylda_comm_init (multi-GPU through the C ABI)
     int comm_world = 1;
@@ -115,6 +117,9 @@ struct pylda_ctx {
     int quad_stream = 1;            // ... with streamed word slots for documents of 225-256 terms
     int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
     int doc_values = 1;             // 1: per-document log-likelihoods complete (see EstepParams::want_doc_ll)
+    int compact = 1;                // the dense quad kernel hands a document to the live-topic kernel (estep_compact.h) once few topics move
+    int compact_cap = 0;            // test hook: hand over at this many live topics at most (0: what the class' register tile holds)
+    int compact_guard_fail = 0;     // test hook: the live-topic kernel's exactness guard fails for every document
     int plan_epoch = 0;
     bool exact_stop = false;        // this E-step's threshold is outside the fixed-point stop test's range
 
@@ -177,6 +182,17 @@ struct pylda_corpus {
     double* d_partial = nullptr;   // nseg x ldk
     int64_t nseg = 0;
     std::vector<int32_t> h_terms_sorted;  // distinct-term counts in schedule order
+    std::vector<int32_t> h_order;         // the schedule: document of every slot
+    // hand-over to the live-topic kernel (launch_compact.hip): per document the live topics and their tile columns
+    int32_t* d_live_n = nullptr;          // D
+    uint16_t* d_live_idx = nullptr;       // D x kLiveStride
+    int64_t* d_tile_ptr = nullptr;        // D
+    double* d_live_tile = nullptr;        // sum over the quad classes' documents of N_d x (live topics the class hands over at)
+    int32_t* d_handoff_it = nullptr;      // D: inner iterations the dense kernel ran before the hand-over, or -1
+    int32_t* d_col_iters = nullptr;       // D: tile columns x iterations the live-topic kernel executed
+    bool compact_ready = false;
+    bool compact_failed = false;          // the tile buffer did not fit: dense kernels only, for good
+    int compact_plan_epoch = -1, compact_cap_used = -1;
     std::vector<Launch> plan;
     int plan_epoch = 0;
     bool plan_exact = false;       // the plan avoids the kernels with the fixed-point stop test
@@ -241,6 +257,11 @@ int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_qfuse(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_qfusek(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_qgroup(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
+
+// ---- launch_compact.hip: the live-topic kernel behind a quad launch class ----
+int compact_handoff_for(const pylda_ctx* ctx, const Launch& L);      // live topics at which the class hands over (0: never)
+int prepare_compact(pylda_ctx* ctx, pylda_corpus* c);                // buffers of the hand-over (sets c->compact_ready)
+int launch_compact(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 
 // ---- sstats_gather.hip ----
 int build_postings(pylda_corpus* c);

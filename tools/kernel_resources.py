@@ -37,3 +37,35 @@ for l in lines:
 for (k, depth, op), n in sorted(spills.items()):
     d = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip()
     print("IN LOOP depth %d: %-56s %-22s x %d" % (depth, d[:56], op, n))
+
+# scratch traffic on the HOT path: basic blocks inside a loop that carry the FMA work (>= 16 fp64 multiply-adds) and
+# touch scratch.  (A cold block inside the loop - the hand-over exit of estep_quad.h - may spill; the iterations may not.)
+def hot_scratch(lines, flt="estep"):
+    out, name, cur = {}, None, None
+    def close():
+        if name and cur and cur["depth"] > 0 and cur["fma"] >= 16 and cur["scratch"] and flt in name:
+            out.setdefault(name, []).append((cur["label"], cur["fma"], cur["scratch"]))
+    for l in lines:
+        m = re.match(r'^(_Z\w+):', l)
+        if m:
+            close()
+            name, cur = m.group(1), None
+            continue
+        s = l.strip()
+        if s.startswith('.LBB') or s.startswith('; %bb.'):
+            close()
+            m = re.search(r'(?:in Loop: Header=\S+|Loop Header:) Depth=(\d+)', l)
+            cur = {"label": s.split()[0], "depth": int(m.group(1)) if m else 0, "fma": 0, "scratch": 0}
+        elif cur is not None:
+            if re.match(r'v_(fma|fmac|mul)_f64', s):
+                cur["fma"] += 1
+            elif s.startswith('scratch_'):
+                cur["scratch"] += 1
+    close()
+    return out
+
+print()
+for k, blocks in hot_scratch(lines, flt).items():
+    d = subprocess.run(['c++filt', k], capture_output=True, text=True).stdout.strip()
+    for label, fma, n in blocks:
+        print("HOT BLOCK %-56s %-12s fma %3d scratch x %d" % (d[:56], label, fma, n))
