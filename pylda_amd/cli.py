@@ -125,14 +125,16 @@ def train_main(argv=None):
     else:
         _initialize_shard(engine, documents, vocabulary, topics, prior_topics, prior_words, rank, world)
     _phase("parse + initial eta", started)
+    whole, whole_at = None, -1
     for _ in range(opt.training_iterations):
         engine.learning()
         if engine._counter % opt.snapshot_interval == 0:
-            whole = _whole_model(engine, group, rank, world)
+            whole, whole_at = _whole_model(engine, group, rank, world), engine._counter
             if rank == 0:
                 whole.export_beta("%sexp_beta-%d" % (run_dir, engine._counter))
                 whole.export_gamma("%sexp_gamma-%d" % (run_dir, engine._counter))
-    whole = _whole_model(engine, group, rank, world, with_corpus=True)
+    # (the last iteration's exports already gathered gamma - 2 GB at cfg 4: the snapshot adds the corpus to that copy)
+    whole = _whole_model(engine, group, rank, world, with_corpus=True, reuse_gamma=whole_at == engine._counter, gathered=whole)
     if rank == 0:
         with open(os.path.join(run_dir, "model-%d" % engine._counter), "wb") as out:
             pickle.dump(whole, out)
@@ -193,9 +195,10 @@ def _host_group():
 
 
 def _line_ranges(documents, world):
-    """Contiguous ranges of the corpus' lines, one per rank, balanced by BYTES (the proxy for distinct terms that is
-    known before parsing; SURVEY 8e balances by nnz): world + 1 line offsets, the same on every rank."""
-    weight = numpy.fromiter((len(line) + 1 for line in documents), dtype=numpy.int64, count=len(documents))
+    """Contiguous ranges of the corpus' lines, one per rank, balanced by TOKENS (blank-separated fields: the proxy for
+    distinct terms that is known before parsing - SURVEY 8e balances by nnz, which needs the vocabulary look-up; bytes,
+    the round-5 proxy, also weigh long words): world + 1 line offsets, the same on every rank."""
+    weight = numpy.fromiter((line.count(" ") + 1 for line in documents), dtype=numpy.int64, count=len(documents))
     ends = numpy.cumsum(weight)
     total = int(ends[-1]) if len(ends) else 0
     bounds = [0]
@@ -216,8 +219,14 @@ def _initialize_shard(engine, documents, vocabulary, topics, prior_topics, prior
     lo, hi = _line_ranges(documents, world)[rank:rank + 2]
     Inferencer._initialize(engine, vocabulary, topics, prior_topics, prior_words)
     engine._parsed_corpus = None
+    verbose, engine._verbose = engine._verbose, False
     engine._train_csr = engine.parse_to_csr(documents[lo:hi])
+    engine._verbose = verbose
     engine._number_of_documents = len(engine._train_csr[0]) - 1
+    parsed = torch.tensor([engine._number_of_documents], dtype=torch.int64)
+    dist.all_reduce(parsed, group=_host_group())
+    if verbose and rank == 0:       # the reference's line (variational_bayes.py:128) with the CORPUS' count, once
+        print("successfully parse %d documents..." % int(parsed))
     engine._gamma = None
     engine._gamma_init_pending = True
     shape = (engine._number_of_topics, engine._number_of_types)
@@ -252,14 +261,19 @@ def _gather_rows(local, rank, world):
     return whole
 
 
-def _whole_model(engine, group, rank, world, with_corpus=False):
+def _whole_model(engine, group, rank, world, with_corpus=False, reuse_gamma=False, gathered=None):
     """The engine the exporters and the snapshot pickle see: at one rank the engine itself; at several, on rank 0, a
     copy that holds the gamma rows of every rank in document order (the shards are contiguous) and - for the snapshot,
-    which like the reference's pickle carries the parsed corpus - the whole corpus, gathered once."""
+    which like the reference's pickle carries the parsed corpus - the whole corpus, gathered once.  reuse_gamma (the
+    same on every rank): `gathered` is what this function returned for an export of the SAME iteration - rank 0 takes
+    its gamma from there, only the corpus travels."""
     if group is None:
         return engine
     import copy
-    gamma = _gather_rows(numpy.asarray(engine._gamma), rank, world)
+    if reuse_gamma:
+        gamma = gathered._gamma_host if rank == 0 else None
+    else:
+        gamma = _gather_rows(numpy.asarray(engine._gamma), rank, world)
     corpus = None
     if with_corpus:
         doc_ptr, term_id, term_ct = engine._train_csr

@@ -418,13 +418,17 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     // safety net: documents the linear-space kernels flagged are redone in log space (the kernel finds them itself)
     if (c->D > 0) {
         p.order = nullptr;
-        const unsigned grid = (unsigned)std::min<int64_t>((c->D + 255) / 256, 4 * (int64_t)ctx->num_cu);
+        // documents per workgroup and step: as many as keep 4 workgroups per CU busy, 256 at most (a small corpus with many
+        // flagged documents - or the force_logspace hook - used to sit on D / 256 workgroups: 8 of 256 CUs at 2000 documents)
+        const int64_t slots = 4 * (int64_t)ctx->num_cu;
+        const int chunk = (int)std::min<int64_t>(256, std::max<int64_t>(1, (c->D + slots - 1) / slots));
+        const unsigned grid = (unsigned)std::min<int64_t>((c->D + chunk - 1) / chunk, slots);
         const size_t list_offset = (logspace_lds_bytes(K) + 15) & ~(size_t)15, lds = list_offset + 257 * sizeof(int32_t);
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(estep_logspace_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(estep_logspace_kernel, dim3(grid), dim3(256), lds, ctx->stream, p, ctx->d_elog, ctx->d_sstats,
-                           c->d_status, c->D, list_offset);
+                           c->d_status, c->D, list_offset, chunk);
     }
     // the corpus-level sums and the number of documents redone, into the four scalars pylda_estep_results reads back
     hipLaunchKernelGGL(vector_sum3_kernel, dim3(4), dim3(1024), 0, ctx->stream, SumJob{c->d_doc_ll, c->D, c->d_scalars},

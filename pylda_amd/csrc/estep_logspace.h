@@ -117,24 +117,26 @@ __device__ inline void logspace_document(const EstepParams& p, const double* __r
 }
 
 // Documents flagged (status == 1) by the fast kernels are found by this kernel itself: the workgroups stride over the
-// status array in chunks of 256 documents, collect a chunk's flagged documents in LDS and redo them one after the other
+// status array in chunks of up to 256 documents, collect a chunk's flagged documents in LDS and redo them one after the other
 // (the whole workgroup works on a document).  Neither the host nor another kernel builds a list: with nothing flagged -
 // every E-step of every BASELINE configuration - the safety net costs ONE dispatch of a few loads per thread.
 //   smem: logspace_lds_bytes(K) bytes for a document, then 256 + 1 ints for the chunk's list.
+// `chunk` (<= 256) documents per workgroup and step: 256 for a large corpus; a small one (associated-press: 2000 documents)
+// is cut finer so that a step with many flagged documents still spreads over the chip (logspace_chunk below).
 __global__ __launch_bounds__(256) void estep_logspace_kernel(EstepParams p,
                                                              const double* __restrict__ elog_wk,
                                                              double* __restrict__ sstats_extra,
                                                              const int32_t* __restrict__ status, int64_t D,
-                                                             size_t list_offset)
+                                                             size_t list_offset, int chunk)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* found = reinterpret_cast<int32_t*>(smem + list_offset);
     int32_t* nfound = found + 256;
-    for (int64_t base = (int64_t)blockIdx.x * 256; base < D; base += (int64_t)gridDim.x * 256) {
+    for (int64_t base = (int64_t)blockIdx.x * chunk; base < D; base += (int64_t)gridDim.x * chunk) {
         if (threadIdx.x == 0) *nfound = 0;
         __syncthreads();
         const int64_t d = base + threadIdx.x;
-        if (d < D && status[d] == 1) found[atomicAdd(nfound, 1)] = (int32_t)d;
+        if ((int)threadIdx.x < chunk && d < D && status[d] == 1) found[atomicAdd(nfound, 1)] = (int32_t)d;
         __syncthreads();
         const int n = *nfound;
         for (int i = 0; i < n; ++i) {                  // (documents are independent: the order inside a chunk does not matter)

@@ -165,7 +165,10 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     for (int s = c; s < Spad; s += kWave) {
         const int n = s * W + wave;
         const bool live = n < N;
-        myoff[s] = (live ? (unsigned long long)p.term_id[lo + n] : 0ull) * row_bytes;   // dead slots: a valid row, count 0 => r = 0
+        // dead slots: the document's own first term with count 0 (r = 0 without a select, and a normaliser that can only
+        // leave the fp64 range when a real term's does - row 0 of the table is not a word of the document, and ITS
+        // normaliser may underflow on a healthy document, which would send the document to the log-space kernel)
+        myoff[s] = (N > 0 ? (unsigned long long)p.term_id[lo + (live ? n : 0)] : 0ull) * row_bytes;     // (an empty document: row 0)
         const double ct = live ? (double)p.term_ct[lo + n] : 0.0;
         mycnt[s] = ct;
         myrr[s] = 0.0;
@@ -233,8 +236,8 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
         // 32-63), so the five remaining reduction levels, the range check and the reciprocal run once for both.
         auto word_pair = [&](const double (&rowA)[KRL], const double (&rowB)[KRL], int slot) {
             const double nrm = half_wave_sum(swap32_add(lane_dot(rowA, tq), lane_dot(rowB, tq)));
-            // (B, t <= 1: a normaliser cannot overflow; NaN fails the compare; an empty slot reads row 0 of the table with
-            //  count 0: a positive normaliser like any word's, r = 0 without a select)
+            // (B, t <= 1: a normaliser cannot overflow; NaN fails the compare; an empty slot reads the document's first term
+            //  with count 0: the normaliser of a real word, r = 0 without a select)
             const double cnt = mycnt[slot + (c >> 5)];
             if (!(nrm > 1e-280)) bad = 1;
             const double r = cnt * rcp_newton(nrm);

@@ -126,3 +126,16 @@ def allreduce_array_(array, group=None):
     t = torch.from_numpy(array)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return array
+
+
+def allreduce_host_array(array, group=None, device=None):
+    """Sum of a host numpy array over the ranks, returned as a host array (the public e_step()/m_step() seam keeps the
+    reference's host-array contract: RCCL reduces a device copy, gloo the array itself)."""
+    import torch
+    import torch.distributed as dist
+    array = np.ascontiguousarray(array, dtype=np.float64)
+    if dist.get_backend(group) == "nccl":
+        t = torch.from_numpy(array).to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy()
+    return allreduce_array_(array.copy(), group)

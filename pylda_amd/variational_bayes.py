@@ -260,7 +260,15 @@ class VariationalBayes(Inferencer):
     def learning(self):
         """One outer VB iteration (variational_bayes.py:239-261), device-resident:
         E-step -> [RCCL all-reduce of the sufficient statistics] -> M-step ->
-        alpha Newton update.  Only scalars and K-vectors cross PCIe."""
+        alpha Newton update.  Only scalars and K-vectors cross PCIe.
+
+        The reference's learning() is a template method: it calls self.e_step(), self.m_step() and
+        self.optimize_hyperparameters() (:243-249), and hybrid.py:23,85 overrides e_step alone.  A subclass (or an
+        instance attribute) that replaces e_step or m_step is therefore honoured: the iteration then runs through
+        the public seam with its host arrays, exactly as the reference does; the fused device path is taken only
+        while both are this class' own."""
+        if self._seam_is_overridden():
+            return self._learning_through_seam()
         self._counter += 1
         ctx = self._context()
         self._push_model()
@@ -309,6 +317,41 @@ class VariationalBayes(Inferencer):
                                           number_of_documents=number_of_documents if group is not None else None)
         clock_m_step = time.time() - clock_m_step + (ctx.elapsed_ms(1, 2) * 1e-3 if timed else 0.0)
 
+        joint_log_likelihood = document_log_likelihood + topic_log_likelihood
+        if self._verbose:
+            print("e_step and m_step of iteration %d finished in %d and %d seconds respectively "
+                  "with log likelihood %g" % (self._counter, clock_e_step, clock_m_step,
+                                              joint_log_likelihood))
+        return joint_log_likelihood
+
+    def _seam_is_overridden(self):
+        cls = type(self)
+        return cls.e_step is not VariationalBayes.e_step or cls.m_step is not VariationalBayes.m_step or \
+            "e_step" in self.__dict__ or "m_step" in self.__dict__
+
+    def _learning_through_seam(self):
+        """learning() as the reference writes it (:239-261): every step through the overridable methods."""
+        self._counter += 1
+        group = self._process_group
+        clock_e_step = time.time()
+        document_log_likelihood, phi_sufficient_statistics = self.e_step()
+        if group is not None:       # document shards: the statistics and the likelihood are sums over the ranks
+            from pylda_amd import distributed
+            phi_sufficient_statistics = distributed.allreduce_host_array(phi_sufficient_statistics, group, self._device)
+        clock_e_step = time.time() - clock_e_step
+        clock_m_step = time.time()
+        topic_log_likelihood, alpha_sufficient_statistics = self.m_step(phi_sufficient_statistics)
+        number_of_documents = None
+        if group is not None:
+            document_log_likelihood, number_of_documents, alpha_sufficient_statistics = distributed.allreduce_small(
+                group, document_log_likelihood, self._number_of_documents, alpha_sufficient_statistics)
+        if self._hyper_parameter_optimize_interval > 0 and \
+                self._counter % self._hyper_parameter_optimize_interval == 0:
+            if number_of_documents is None:
+                self.optimize_hyperparameters(alpha_sufficient_statistics)
+            else:
+                self.optimize_hyperparameters(alpha_sufficient_statistics, number_of_documents=number_of_documents)
+        clock_m_step = time.time() - clock_m_step
         joint_log_likelihood = document_log_likelihood + topic_log_likelihood
         if self._verbose:
             print("e_step and m_step of iteration %d finished in %d and %d seconds respectively "

@@ -50,6 +50,43 @@ def test_learning_trace_matches_reference(ap_model, ap_train):
     assert m._counter == n
 
 
+def test_learning_honours_an_overridden_e_step(ap_train):
+    """The reference's learning() dispatches through self.e_step() / self.m_step() (variational_bayes.py:243-247) and
+    hybrid.py:23,85 overrides e_step alone: a subclass that wraps e_step (or an instance that patches m_step) must see
+    one call per learning(), and - perturbing nothing - the reference's trace must come out unchanged."""
+    from pylda_amd.variational_bayes import VariationalBayes
+    tr = load_golden("ap_trace_k10.npz")
+
+    class Counting(VariationalBayes):
+        calls = 0
+
+        def e_step(self, parsed_corpus=None, local_parameter_iteration=50, local_parameter_converge_threshold=1e-6):
+            if parsed_corpus is None:
+                Counting.calls += 1
+            return VariationalBayes.e_step(self, parsed_corpus, local_parameter_iteration, local_parameter_converge_threshold)
+
+    g = ap_train
+    words = [str(w) for w in g["words"]]
+    docs = documents_from_csr(words, g["doc_ptr"], g["term_id"], g["term_ct"])
+    np.random.seed(int(tr["seed"]))
+    m = Counting()
+    m._verbose = False
+    m._initialize(docs, words, 10, 1.0 / 10, 1.0 / len(words))
+    assert m._seam_is_overridden()
+    m_calls = []
+    for it in range(3):
+        if it == 2:                     # ... and a method patched on the INSTANCE counts too
+            inner = m.m_step
+            m.m_step = lambda sstats: (m_calls.append(sstats.shape), inner(sstats))[1]
+        joint = m.learning()
+        assert abs(joint - tr["joint_ll"][it]) < 1e-8 * abs(tr["joint_ll"][it]), it
+        assert rel_err(m._alpha_alpha, tr["alpha"][it]) < 1e-8, it
+    assert Counting.calls == 3 and m._counter == 3
+    assert m_calls == [(10, 6806)]
+    plain = VariationalBayes()
+    assert not plain._seam_is_overridden()
+
+
 def test_hundred_iteration_trace_and_heldout(ap_train, ap_test):
     """BASELINE.json cfg 1/2 end to end: 100 learning() iterations on AP K=10 from the reference's
     seeded initial state reproduce its joint log-likelihood and alpha traces, then its held-out

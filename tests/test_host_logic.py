@@ -329,3 +329,39 @@ def test_traffic_hash_covers_every_device_header_of_the_estep():
             now = bench.kernel_source_hash(copy)
             assert now != base, h
             base = now
+
+
+def test_learning_detects_an_overridden_seam():
+    """learning() takes the fused device path only while e_step / m_step are the class' own (the reference dispatches
+    through self.e_step() / self.m_step(): variational_bayes.py:243-247, hybrid.py:23,85): the detection, and the
+    reference's order of calls through the seam, without a GPU."""
+    from pylda_amd.variational_bayes import VariationalBayes
+    calls = []
+
+    class Wrapped(VariationalBayes):
+        def e_step(self, parsed_corpus=None, local_parameter_iteration=50, local_parameter_converge_threshold=1e-6):
+            calls.append("e")
+            return -10.0, np.ones((2, 3))
+
+        def m_step(self, phi_sufficient_statistics):
+            calls.append(("m", phi_sufficient_statistics.shape))
+            return -5.0, np.array([1.0, 2.0])
+
+        def optimize_hyperparameters(self, alpha_sufficient_statistics, **kwargs):
+            calls.append(("a", tuple(alpha_sufficient_statistics)))
+
+    m = Wrapped()
+    m._verbose = False
+    m._counter = 0
+    assert m._seam_is_overridden()
+    assert m.learning() == -15.0                       # :252 joint = document + topic log-likelihood
+    assert calls == ["e", ("m", (2, 3)), ("a", (1.0, 2.0))] and m._counter == 1
+    m._hyper_parameter_optimize_interval = 2           # :247: every second iteration only
+    calls.clear()
+    m.learning()
+    m.learning()
+    assert [c for c in calls if c[0] == "a"] == [("a", (1.0, 2.0))]
+    plain = VariationalBayes()
+    assert not plain._seam_is_overridden()
+    plain.e_step = lambda *a, **k: None                # a method patched on the instance counts as well
+    assert plain._seam_is_overridden()

@@ -3,9 +3,10 @@
 # WRITE_SIZE passes of cfg 4, cfg 3, cfg 5 and associated-press with the kernels as they are NOW, the traffic files bench.py ties
 # to the hash of the device headers, then the default bench line (which therefore carries roofline.traffic), the
 # --steps 20 --warmup 5 line and the GPU suite.  Everything lands under gpurun_out/; copy into profiles/ with
-#   python tools/finalize_round.sh --collect r05        (here, after the call has merged gpurun_out/)
+#   bash tools/finalize_round.sh --collect r05        (here, after the call has merged gpurun_out/)
 TAG=${1:-rXX}
 if [ "$TAG" = "--collect" ]; then
+    set -euo pipefail      # a missing gpurun_out file must not leave a stale profiles/traffic_*.json behind
     TAG=$2
     for n in cfg4 cfg3; do
         cp gpurun_out/prof_${TAG}_$n/summary.txt profiles/${TAG}_${n}_rocprof_summary.txt
