@@ -249,8 +249,12 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         ctx->plan_epoch += 1;
     } else if (!strcmp(name, "doc_values")) {
         ctx->doc_values = value != 0;
+    } else if (!strcmp(name, "gather_live")) {       // (takes effect for corpora whose postings are built afterwards)
+        ctx->gather_live = value != 0;
     } else if (!strcmp(name, "compact")) {
         ctx->compact = value != 0;
+    } else if (!strcmp(name, "compact_phase")) {
+        ctx->compact_phase = value != 0;
     } else if (!strcmp(name, "compact_cap")) {
         if (value < 0 || value > kLiveStride) return fail(ctx, PYLDA_ERR_INVALID, "compact_cap=%lld: 0 .. %d", (long long)value, kLiveStride);
         ctx->compact_cap = (int)value;
@@ -425,15 +429,12 @@ int pylda_elapsed_ms(pylda_ctx* ctx, int slot_from, int slot_to, double* ms)
 
 namespace {
 // the four work counters of the profiled E-steps since the last read (doc_terms.h work_count_kernel), read and reset
-int fetch_work(pylda_ctx* ctx, double (&w)[4])
+int fetch_work(pylda_ctx* ctx)
 {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!ctx->work_cached) {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->work_cache, ctx->d_work, sizeof ctx->work_cache, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof ctx->work_cache, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    for (int i = 0; i < 4; ++i) w[i] = ctx->work_cache[i];
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->work_cache, ctx->d_work, sizeof ctx->work_cache, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof ctx->work_cache, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PYLDA_OK;
 }
 }  // namespace
@@ -441,24 +442,24 @@ int fetch_work(pylda_ctx* ctx, double (&w)[4])
 int pylda_work_counters(pylda_ctx* ctx, double* inner_iterations, double* inner_iteration_terms)
 {
     if (!ctx) return PYLDA_ERR_INVALID;
-    double w[4];
-    const int rc = fetch_work(ctx, w);
+    const int rc = fetch_work(ctx);
     if (rc != PYLDA_OK) return rc;
-    ctx->work_cached = true;            // (pylda_executed_work reports the other half of the same read)
-    if (inner_iterations) *inner_iterations = w[0];
-    if (inner_iteration_terms) *inner_iteration_terms = w[1];
+    ctx->work_cached = true;            // (pylda_executed_work reports the other half of this read)
+    if (inner_iterations) *inner_iterations = ctx->work_cache[0];
+    if (inner_iteration_terms) *inner_iteration_terms = ctx->work_cache[1];
     return PYLDA_OK;
 }
 
 int pylda_executed_work(pylda_ctx* ctx, double* tile_entries, double* handed_over)
 {
     if (!ctx) return PYLDA_ERR_INVALID;
-    double w[4];
-    const int rc = fetch_work(ctx, w);
-    if (rc != PYLDA_OK) return rc;
+    if (!ctx->work_cached) {            // not behind pylda_work_counters: a read (and reset) of its own
+        const int rc = fetch_work(ctx);
+        if (rc != PYLDA_OK) return rc;
+    }
     ctx->work_cached = false;
-    if (tile_entries) *tile_entries = w[2];
-    if (handed_over) *handed_over = w[3];
+    if (tile_entries) *tile_entries = ctx->work_cache[2];
+    if (handed_over) *handed_over = ctx->work_cache[3];
     return PYLDA_OK;
 }
 

@@ -34,11 +34,18 @@ __global__ __launch_bounds__(256) void doc_terms_kernel(EstepParams p, int64_t c
     const double* gamma = p.gamma + (size_t)doc * K;
     const double* t = p.tfinal + (size_t)doc * p.ldk;
     double lgam = 0.0, gsum = 0.0, term2 = 0.0, term3 = 0.0;
+    // a document the live-topic kernel finished keeps t as a list of its live topics (a dead topic has mass 0: no term)
+    const int listed = p.live_stats ? p.live_n[doc] : -1;
     for (int k = lane; k < K; k += kWave) {
         const double g = gamma[k], mass = g - p.alpha[k];                 // = t_k * sum_n r_n B[w_n][k]
         lgam += lgamma_pos(g);
         gsum += g;
-        if (mass != 0.0) term2 = fma(log(t[k]), mass, term2);             // (t_k may have underflowed where the mass did)
+        if (listed < 0 && mass != 0.0) term2 = fma(log(t[k]), mass, term2);   // (t_k may have underflowed where the mass did)
+    }
+    if (lane < listed) {
+        const int k = live_idx_of(p.live_list, doc)[lane];
+        const double mass = gamma[k] - p.alpha[k];
+        if (mass != 0.0) term2 = fma(log(live_t_of(p.live_list, doc)[lane]), mass, term2);
     }
     const int64_t lo = p.doc_ptr[doc], hi = p.doc_ptr[doc + 1];
     for (int64_t n = lo + lane; n < hi; n += kWave) {

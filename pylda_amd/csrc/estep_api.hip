@@ -181,7 +181,7 @@ void pylda_corpus_destroy(pylda_corpus* c)
     c->d_post_pos = nullptr;
     dev_free(c->d_seg_begin); dev_free(c->d_seg_end); dev_free(c->d_word_seg_ptr); dev_free(c->d_partial); dev_free(c->d_exec_order);
     dev_free(c->d_seg_block); dev_free(c->d_term_of); dev_free(c->d_rendezvous);
-    dev_free(c->d_live_n); dev_free(c->d_live_idx); dev_free(c->d_tile_ptr); dev_free(c->d_live_tile);
+    dev_free(c->d_live_n); dev_free(c->d_live_list); dev_free(c->d_tile_ptr); dev_free(c->d_live_tile);
     dev_free(c->d_handoff_it); dev_free(c->d_col_iters);
     delete c;
 }
@@ -211,6 +211,14 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
 
     int rc = enqueue_prepare(ctx, heldout != 0);                      // :152-155
     if (rc != PYLDA_OK) return rc;
+    // the launch plan of this E-step, then the hand-over buffers of the live-topic kernel (estep_compact.h), then - first
+    // training E-step only - the postings, whose layout depends on whether the corpus hands documents over
+    {
+        const double span = tol * K;
+        ctx->exact_stop = !(span >= 3.725290298461914e-09 /* 2^-28 */ && span < 1024.0);
+    }
+    if (c->plan_epoch != ctx->plan_epoch || c->plan_exact != ctx->exact_stop) build_plan(c);
+    if ((rc = prepare_compact(ctx, c)) != PYLDA_OK) return rc;
     if (!heldout && (rc = build_postings(c)) != PYLDA_OK) return rc;
 
     EstepParams p;
@@ -244,11 +252,6 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     p.status = c->d_status;
     p.term_scratch = c->d_term_scratch;
 
-    {
-        const double span = tol * K;
-        ctx->exact_stop = !(span >= 3.725290298461914e-09 /* 2^-28 */ && span < 1024.0);
-    }
-    if (c->plan_epoch != ctx->plan_epoch || c->plan_exact != ctx->exact_stop) build_plan(c);
     if (!c->d_term_scratch)
         for (const Launch& L : c->plan)
             if (L.variant == kGenericHuge) {
@@ -257,11 +260,11 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
                 p.term_scratch = c->d_term_scratch;
                 break;
             }
-    // hand-over to the live-topic kernel (estep_compact.h): buffers, and the per-document work counters of this E-step
-    if ((rc = prepare_compact(ctx, c)) != PYLDA_OK) return rc;
+    // hand-over to the live-topic kernel: its buffers, and the per-document work counters of this E-step
     p.handoff_live = 0;
     p.live_n = c->d_live_n;
-    p.live_idx = c->d_live_idx;
+    p.live_list = c->d_live_list;
+    p.live_stats = (!heldout && c->live_stats) ? 1 : 0;
     p.live_tile = c->d_live_tile;
     p.tile_ptr = c->d_tile_ptr;
     p.handoff_it = c->d_handoff_it;
@@ -272,6 +275,8 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         HIP_TRY(ctx, hipMemsetAsync(c->d_handoff_it, 0xff, (size_t)c->D * sizeof(int32_t), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(c->d_col_iters, 0, (size_t)c->D * sizeof(int32_t), ctx->stream));
     }
+    // (-1: the document's t is its dense row - until the live-topic kernel finishes it and leaves a list)
+    if (p.live_stats) HIP_TRY(ctx, hipMemsetAsync(c->d_live_n, 0xff, (size_t)c->D * sizeof(int32_t), ctx->stream));
     auto open_bracket = [&](int slot, hipStream_t st) -> int {      // index into pending_events, or -1
         if (!ctx->profiling) return -1;
         pylda_ctx::Bracket br{take_event(ctx), take_event(ctx), slot};
@@ -342,8 +347,9 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
                         (long long)L.count, p.handoff_live, hipGetErrorString(e));
             }
             // ... and behind it, on the same stream, the live-topic kernel for the documents the class handed over
-            if (rc == PYLDA_OK && p.handoff_live > 0) rc = launch_compact(ctx, p, L);
-            if (debug_sync && p.handoff_live > 0) {
+            // (option compact_phase 0; the default runs them as a phase of their own behind all dense kernels, below)
+            if (rc == PYLDA_OK && p.handoff_live > 0 && !ctx->compact_phase) rc = launch_compact(ctx, p, L);
+            if (debug_sync && p.handoff_live > 0 && !ctx->compact_phase) {
                 const hipError_t e = hipStreamSynchronize(ctx->stream);
                 fprintf(stderr, "[pylda debug] class %d live-topic kernel: %s\n", slot, hipGetErrorString(e));
             }
@@ -369,6 +375,36 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             }
         }
         join();
+        // The live-topic kernels as a phase of their own.  A dense quad workgroup needs a whole CU (at K = 256: its eight
+        // wavefronts hold the CU's register file), a live-topic wavefront an eighth of one: side by side on the chip, a
+        // CU that holds even one live-topic wavefront cannot take a dense document, and the dense kernels - 90 % of
+        // the document time - ran on what was left (measured on 200k cfg 4 documents: 38.7 ms mixed).  Behind the join
+        // the two never meet.  One launch per lane shape (term slots per lane): the classes of a shape are contiguous in
+        // the schedule.
+        if (c->compact_ready && ctx->compact_phase) {
+            Launch group[5];
+            for (Launch& g : group) g.count = 0;
+            for (const Launch& L : c->plan) {
+                if (compact_handoff_for(ctx, L) <= 0) continue;
+                Launch& g = group[std::min(4, std::max(1, (L.n_cap + kWave - 1) / kWave))];
+                if (g.count == 0) {
+                    g = L;
+                } else {
+                    const int64_t lo = std::min(g.first, L.first), hi = std::max(g.first + g.count, L.first + L.count);
+                    g.first = lo;
+                    g.count = hi - lo;
+                    g.n_cap = std::max(g.n_cap, L.n_cap);
+                }
+            }
+            for (const Launch& g : group) {
+                if (g.count == 0) continue;
+                p.order = c->d_order + g.first;
+                p.n_cap = g.n_cap;
+                p.handoff_live = compact_handoff_for(ctx, g);
+                if ((rc = launch_compact(ctx, p, g)) != PYLDA_OK) return rc;
+            }
+            p.handoff_live = 0;
+        }
     }
     // the document terms the register kernels left out on the training fast path (status 3; doc_terms.h): one wavefront
     // per document, fp64-VALU bound.  Beside the dispatch-paced statistics gather (L2-bound) it runs on an auxiliary

@@ -43,8 +43,10 @@ struct EstepParams {
     double* term_scratch;     // nnz scratch doubles, only for documents too long for the LDS (estep_generic.h MODE 2)
     // ---- hand-over to the live-topic kernel (estep_compact.h); handoff_live == 0: never ----
     int handoff_live;         // a document leaves the dense kernel once at most this many topics have gamma_k != alpha_k
-    int32_t* live_n;          // D out: live topics of a document handed over (status 4)
-    uint16_t* live_idx;       // D x kLiveStride out: their indices, ascending
+    int32_t* live_n;          // D: live topics of a document handed over (status 4); after the E-step: entries of its list of t
+                              //    (live_stats), -1: the document's t is the dense row tfinal[d]
+    char* live_list;          // D x kLiveListBytes: topic indices (uint16 x kLiveStride), then t of the last iteration (double x kLiveStride)
+    int live_stats;           // 1: the statistics pass reads the lists (sstats_live.h): the live-topic kernel writes no dense row
     double* live_tile;        // the document's compact tile: value of term n, live topic j at live_tile[tile_ptr[d] + j * N_d + n]
     const int64_t* tile_ptr;  // D offsets into live_tile (doubles)
     double alpha_max, alpha_min;   // over the K topics (the exactness guard of the live-topic kernel)
@@ -52,7 +54,14 @@ struct EstepParams {
     int32_t* col_iters;       // D out: sum over the live-topic kernel's iterations of the tile columns it ran them on
 };
 
-constexpr int kLiveStride = 32;   // entries per document in live_idx: the largest live set the live-topic kernel takes over
+constexpr int kLiveStride = 32;   // entries per document's list: the largest live set the live-topic kernel takes over
+// A document's list: [uint16 topic x 32][double t x 32] - the indices and the first eight t share the first 128 bytes
+constexpr int kLiveListBytes = kLiveStride * 2 + kLiveStride * 8;
+__device__ __forceinline__ uint16_t* live_idx_of(char* live_list, int64_t doc) { return reinterpret_cast<uint16_t*>(live_list + doc * kLiveListBytes); }
+__device__ __forceinline__ double* live_t_of(char* live_list, int64_t doc)
+{
+    return reinterpret_cast<double*>(live_list + doc * kLiveListBytes + kLiveStride * 2);
+}
 
 // Sum over the 64 lanes, result in every lane, without the LDS crossbar (ds_bpermute costs an LDS
 // round trip per level): four DPP levels inside each 16-lane row, then one permlane16 and one

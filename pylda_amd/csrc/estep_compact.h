@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
     const int L0 = p.live_n[doc];
 
     if (lane < L0) {
-        const int topic = p.live_idx[(size_t)doc * kLiveStride + lane];
+        const int topic = live_idx_of(p.live_list, doc)[lane];
         lds.idx[lane] = topic;
         lds.col[lane] = lane;
         lds.gam[lane] = p.gamma[(size_t)doc * K + topic];
@@ -400,14 +400,19 @@ __global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
     if (__ballot(st.bad != 0) != 0ull) {
         if (!p.heldout) {      // contributes nothing to the gather pass; the log-space kernel adds it
             for (int n = lane; n < N; n += kWave) p.rfinal[lo + n] = 0.0;
-            for (int k = lane; k < ldk; k += kWave) p.tfinal[(size_t)doc * ldk + k] = 0.0;
+            if (p.live_stats) {
+                if (lane == 0) p.live_n[doc] = 0;
+            } else {
+                for (int k = lane; k < ldk; k += kWave) p.tfinal[(size_t)doc * ldk + k] = 0.0;
+            }
         }
         if (lane == 0) p.status[doc] = 1;
         return;
     }
 
-    // the row of t for the statistics pass: t of the last executed iteration at the live topics, 0 elsewhere (a dead
-    // topic's 1e-114 is below the last bit of every statistic it would touch: eta = statistics + beta is unchanged)
+    // t of the last executed iteration for the statistics pass: the document's LIST (live_stats: 10 bytes per live topic
+    // instead of a 2-KiB row) or the dense row with 0 at the dead topics - whose 1e-114 is below the last bit of every
+    // statistic it would touch either way: eta = statistics + beta is unchanged
     const bool mine = lane < L;
     const int at = mine ? lane : 0;
     const int topic = lds.idx[at];
@@ -415,11 +420,19 @@ __global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
     if (mine) p.gamma[(size_t)doc * K + topic] = gam;
     if (lane == 0) p.col_iters[doc] = st.cols;
     if (!p.heldout) {
-        for (int k = lane; k < ldk; k += kWave) trow[k] = 0.0;
-        wave_lds_exchange();
-        if (mine) trow[topic] = tlast;
-        wave_lds_exchange();
-        for (int k = lane; k < ldk; k += kWave) p.tfinal[(size_t)doc * ldk + k] = trow[k];
+        if (p.live_stats) {
+            if (mine) {
+                live_idx_of(p.live_list, doc)[lane] = (uint16_t)topic;
+                live_t_of(p.live_list, doc)[lane] = tlast;
+            }
+            if (lane == 0) p.live_n[doc] = L;
+        } else {
+            for (int k = lane; k < ldk; k += kWave) trow[k] = 0.0;
+            wave_lds_exchange();
+            if (mine) trow[topic] = tlast;
+            wave_lds_exchange();
+            for (int k = lane; k < ldk; k += kWave) p.tfinal[(size_t)doc * ldk + k] = trow[k];
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int n = s * kWave + lane;

@@ -106,7 +106,7 @@ __device__ __forceinline__ void quad_hand_over(const EstepParams& p, char* smem,
         int at = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
         for (int w = 0; w < trank; ++w) at += (int)wcount[w];
         pos[ktid] = alive ? at : -1;
-        if (alive) p.live_idx[(size_t)doc * kLiveStride + at] = (uint16_t)ktid;
+        if (alive) live_idx_of(p.live_list, doc)[at] = (uint16_t)ktid;
         if (ktid < K) p.gamma[(size_t)doc * K + ktid] = gam;
     }
     __syncthreads();
@@ -120,6 +120,7 @@ __device__ __forceinline__ void quad_hand_over(const EstepParams& p, char* smem,
     }
     const double2* rows = reinterpret_cast<const double2*>(smem + L::rows) + (size_t)gg * TWL * (KT / 2) + c;
     // topic by topic of this lane's eight (2 c + 2 TL jj + {0, 1}): its column, then the lane's terms
+#ifndef PYLDA_EXPERIMENT_NO_TILE      // (timing probe: what the tile stores of the hand-over cost - the results are wrong without them)
     static_for<KRL>([&](auto idx) {
         constexpr int j = decltype(idx)::value;
         const int at = pos[2 * (c + TL * (j / 2)) + (j & 1)];
@@ -138,6 +139,7 @@ __device__ __forceinline__ void quad_hand_over(const EstepParams& p, char* smem,
             }
         }
     });
+#endif
     if (tid == 0) {
         unsigned total_live = 0;
         for (int w = 0; w < KT / kWave; ++w) total_live += wcount[w];

@@ -118,6 +118,8 @@ struct pylda_ctx {
     int quilt_odd = 1;              // words-per-lane 6 / 7 instantiations (less padding for 129..224-term documents)
     int doc_values = 1;             // 1: per-document log-likelihoods complete (see EstepParams::want_doc_ll)
     int compact = 1;                // the dense quad kernel hands a document to the live-topic kernel (estep_compact.h) once few topics move
+    int gather_live = 1;            // the statistics pass reads the documents' lists of live topics (sstats_live.h) where the corpus hands documents over
+    int compact_phase = 1;          // the live-topic kernels run behind ALL dense kernels of the E-step (0: behind their class, on its stream)
     int compact_cap = 0;            // test hook: hand over at this many live topics at most (0: what the class' register tile holds)
     int compact_guard_fail = 0;     // test hook: the live-topic kernel's exactness guard fails for every document
     int plan_epoch = 0;
@@ -185,7 +187,8 @@ struct pylda_corpus {
     std::vector<int32_t> h_order;         // the schedule: document of every slot
     // hand-over to the live-topic kernel (launch_compact.hip): per document the live topics and their tile columns
     int32_t* d_live_n = nullptr;          // D
-    uint16_t* d_live_idx = nullptr;       // D x kLiveStride
+    char* d_live_list = nullptr;          // D x kLiveListBytes: a document's live topics and their t
+    bool live_stats = false;              // the statistics pass of this corpus reads those lists (decided with the postings)
     int64_t* d_tile_ptr = nullptr;        // D
     double* d_live_tile = nullptr;        // sum over the quad classes' documents of N_d x (live topics the class hands over at)
     int32_t* d_handoff_it = nullptr;      // D: inner iterations the dense kernel ran before the hand-over, or -1

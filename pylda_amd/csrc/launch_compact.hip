@@ -59,7 +59,7 @@ int prepare_compact(pylda_ctx* ctx, pylda_corpus* c)
     auto A = [&](int r) { if (rc == PYLDA_OK) rc = r; };
     if (!c->d_live_n) {
         A(dev_alloc(ctx, &c->d_live_n, (size_t)c->D));
-        A(dev_alloc(ctx, &c->d_live_idx, (size_t)c->D * kLiveStride));
+        A(dev_alloc(ctx, &c->d_live_list, (size_t)c->D * kLiveListBytes));
         A(dev_alloc(ctx, &c->d_tile_ptr, (size_t)c->D));
         A(dev_alloc(ctx, &c->d_handoff_it, (size_t)c->D));
         A(dev_alloc(ctx, &c->d_col_iters, (size_t)c->D));

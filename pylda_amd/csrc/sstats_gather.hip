@@ -3,6 +3,7 @@
 #include "host_internal.h"
 #include "sstats_kernels.h"
 #include "sstats_sweep.h"
+#include "sstats_live.h"
 
 namespace pylda_host {
 
@@ -158,7 +159,11 @@ int build_postings(pylda_corpus* c)
     timer.lap("postings on the device");
 
     const GatherConfig g = gather_config(ctx, c);
-    int NB = document_blocks(g);
+    // Documents the live-topic kernel finishes leave a LIST of their live topics instead of a row of t (sstats_live.h):
+    // with that the pass is one plain walk of the postings - no document blocks, no sweep.  Decided here, with the
+    // postings: the corpus hands documents over at this, its first training E-step (prepare_compact ran before us).
+    c->live_stats = ctx->gather_live && c->compact_ready && (size_t)4 * ctx->ldk * sizeof(double) <= 64 * 1024;
+    int NB = c->live_stats ? 1 : document_blocks(g);
     // (the gather kernel family is fixed here, with the postings: the partial rows, the rounds and seg_lo are sized for it,
     //  so a later change of the option must not change the kernel that walks them)
     c->gather_rows = ctx->gather_rows;
@@ -173,7 +178,7 @@ int build_postings(pylda_corpus* c)
         PYLDA_SWEEP_DISPATCH(ctx, c, SWEEP_OCC);
 #undef SWEEP_OCC
     }
-    const bool want_sweep = sweep_wanted(g, document_blocks(g), per_cu >= 1);
+    const bool want_sweep = !c->live_stats && sweep_wanted(g, document_blocks(g), per_cu >= 1);
     if (want_sweep) NB = sweep_blocks(g, NB);
 
     SegmentCut cut;
@@ -276,6 +281,30 @@ static void fill_sweep_params(pylda_ctx* ctx, pylda_corpus* c, SweepParams& sp)
 int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
 {
     const int ldk = ctx->ldk;
+    if (c->live_stats) {
+        // (every E-step of this corpus: a document without a list - live_n = -1, reset by pylda_estep - adds its row)
+        const pylda_corpus::Round& r = c->rounds.front();
+        const dim3 grid((unsigned)((c->nseg + 3) / 4));
+        const size_t lds = (size_t)4 * ldk * sizeof(double);
+        if (c->nseg > 0) {
+#define LIVE_ARGS c->d_seg_begin, c->d_seg_end, c->nseg, c->d_post_doc
+#define LIVE_TAIL c->d_tfinal, c->d_rfinal, c->d_live_n, c->d_live_list, ldk, c->d_partial
+            if (c->wide_pos)
+                hipLaunchKernelGGL((sstats_gather_live_kernel<4, int64_t>), grid, dim3(256), lds, ctx->stream, LIVE_ARGS,
+                                   static_cast<const int64_t*>(c->d_post_pos), LIVE_TAIL);
+            else
+                hipLaunchKernelGGL((sstats_gather_live_kernel<4, int32_t>), grid, dim3(256), lds, ctx->stream, LIVE_ARGS,
+                                   static_cast<const int32_t*>(c->d_post_pos), LIVE_TAIL);
+#undef LIVE_ARGS
+#undef LIVE_TAIL
+        }
+        if (r.ent_blocks > 0)
+            hipLaunchKernelGGL(sstats_finalize_kernel, dim3((unsigned)r.ent_blocks), dim3(256), 0, ctx->stream,
+                               c->d_word_seg_ptr, c->d_partial, ctx->d_expElog, ctx->d_expElog_elog, r.w_first, r.n_words, ldk,
+                               r.seg_lo, ctx->d_sstats, c->d_entropy_partial + r.ent_first);
+        HIP_TRY(ctx, hipGetLastError());
+        return PYLDA_OK;
+    }
     if (c->sweep) {
         SweepParams sp;
         fill_sweep_params(ctx, c, sp);
