@@ -57,7 +57,8 @@ if ROOT not in sys.path:
 import numpy as np
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
-FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec), at ...
+PEAK_CLOCK_MHZ = 2400.0         # ... the peak engine clock (MI355X_MICROARCH.md)
 CHUNK = 25000
 PROTOCOL_WARMUP = 3             # three warm-up outer iterations ...
 PROTOCOL_WINDOW = 5             # ... then outer iterations 4-8 are the timed window
@@ -149,24 +150,33 @@ def build_workload(name, rank, world, device, docs_override=None):
     raise SystemExit("unknown workload %r" % name)
 
 
-def cpu_baseline(alpha, eta, ptr, ids, cts, budget_s, max_docs):
-    """The reference's algorithm on the host CPU: numpy restatement (what the
-    reference itself executes), single thread, on a bounded prefix of the corpus."""
+def cpu_baseline(alpha, eta, ptr, ids, cts, budget_s, max_docs, repeats=3):
+    """The reference's algorithm on the host CPU: numpy restatement (what the reference itself executes), single
+    thread, on a FIXED prefix of the corpus timed `repeats` times - the figure is the MEDIAN (a time-boxed prefix timed
+    once swung 1.8x between runs on the GPU box's shared host).  The prefix is sized by one probe of 20 documents so
+    that the leg stays within ~budget_s of CPU time: documents = budget / repeats x the probe's rate, at most max_docs."""
     from oracle import vb_numpy
     E_log_eta = vb_numpy.compute_dirichlet_expectation(eta)
-    doc_ll = []
-    t0 = time.perf_counter()
-    n = 0
-    while n < max_docs and n < len(ptr) - 1:
-        lo, hi = int(ptr[n]), int(ptr[n + 1])
-        _, ll, _, _, _ = vb_numpy.e_step_document(alpha, E_log_eta, ids[lo:hi].astype(np.int64),
-                                                  cts[lo:hi])
-        doc_ll.append(ll)
-        n += 1
-        if time.perf_counter() - t0 > budget_s and n >= 20:
-            break
-    elapsed = time.perf_counter() - t0
-    return n / elapsed, n, np.array(doc_ll)
+    D = len(ptr) - 1
+
+    def run(n):
+        out = []
+        t0 = time.perf_counter()
+        for d in range(n):
+            lo, hi = int(ptr[d]), int(ptr[d + 1])
+            _, ll, _, _, _ = vb_numpy.e_step_document(alpha, E_log_eta, ids[lo:hi].astype(np.int64), cts[lo:hi])
+            out.append(ll)
+        return time.perf_counter() - t0, np.array(out)
+
+    probe = min(20, D)
+    t_probe, _ = run(probe)
+    n = int(max(probe, min(max_docs, D, budget_s / repeats / (t_probe / probe))))
+    n = min(n, 200) if n >= 200 else n          # (200 documents when the budget allows: the same sample from run to run)
+    times, doc_ll = [], None
+    for _ in range(repeats):
+        t, doc_ll = run(n)
+        times.append(t)
+    return n / float(np.median(times)), n, doc_ll
 
 
 def cpu_baseline_all_cores(alpha, eta, ptr, ids, cts, budget_s, workers, docs_per_worker=600):
@@ -204,12 +214,15 @@ def cpu_baseline_all_cores(alpha, eta, ptr, ids, cts, budget_s, workers, docs_pe
     return rate, done, ok
 
 
-def c_oracle_rate(alpha, eta, ptr, ids, cts, n):
+def c_oracle_rate(alpha, eta, ptr, ids, cts, n, repeats=3):
     from oracle import c_oracle
     c_oracle.load()
-    t0 = time.perf_counter()
-    c_oracle.e_step(alpha, eta, ptr[:n + 1], ids[:ptr[n]], cts[:ptr[n]])
-    return n / (time.perf_counter() - t0)
+    times = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        c_oracle.e_step(alpha, eta, ptr[:n + 1], ids[:ptr[n]], cts[:ptr[n]])
+        times.append(time.perf_counter() - t0)
+    return n / float(np.median(times))
 
 
 class Job(object):
@@ -292,6 +305,7 @@ def measure(job, args, name, steps, warmup, docs=None):
     # M-step, nothing is cached.  --warmup beyond 3 runs further window steps untimed.
     t_first = time.perf_counter()
     t_step1 = None
+    steady = name.startswith("synth")
     for _ in range(PROTOCOL_WARMUP):
         vb.learning()
         if t_step1 is None:
@@ -315,6 +329,20 @@ def measure(job, args, name, steps, warmup, docs=None):
     for _ in range(max(0, warmup - PROTOCOL_WARMUP)):
         window_step()
     job.torch.cuda.synchronize()
+    # ... and untimed steps of the same window until the process has run >= 2 s of them (large corpora: none needed): the
+    # timed steps - and the shard proxies, which do the same - run at the clock the chip SUSTAINS under this load
+    if steady:
+        def one_window():
+            t0 = time.perf_counter()
+            for _ in range(PROTOCOL_WINDOW):
+                window_step()
+            job.torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        # (the same count on every rank - a step holds collectives: the slowest rank's first window sizes the rest)
+        t_window = job.reduce([one_window()], "max")[0]
+        for _ in range(int(np.ceil(2.0 / max(t_window, 1e-3))) - 1):
+            one_window()
+    state["pos"] = PROTOCOL_WINDOW              # (the timed region starts at the window's first iteration)
     ctx.set_profiling(True)
     ctx.kernel_time()
     ctx.work_counters()
@@ -330,6 +358,8 @@ def measure(job, args, name, steps, warmup, docs=None):
     elapsed = time.perf_counter() - stamps[0]
     doc_ms, ss_ms, calls = ctx.kernel_time()
     sum_iters, sum_iter_terms = ctx.work_counters()
+    tile_entries, handed_over = ctx.executed_work()          # (the same read of the device counters)
+    clock_mhz = ctx.shader_clock_mhz()
     classes = vb._train_corpus.plan()
     ctx.set_profiling(False)
     step_ms = np.diff(np.array(stamps)) * 1e3
@@ -351,6 +381,10 @@ def measure(job, args, name, steps, warmup, docs=None):
     traffic, traffic_source = traffic_record(name if docs is None else None)
     flops = 4.0 * K * sum_iter_terms / calls          # two mat-vecs per inner iteration actually executed, rank 0
     tflops = flops / (doc_ms * 1e-3) / 1e12 if doc_ms > 0 else 0.0
+    # ... of which the kernels ran only the live part through the FMA pipes: the dense kernels K columns per term and
+    # iteration, the live-topic kernel (estep_compact.h) the columns of its tile; the rest are the dead topics' exact zeros
+    executed = 4.0 * tile_entries / calls
+    peak_at_clock = FP64_VECTOR_PEAK_TFLOPS * clock_mhz / PEAK_CLOCK_MHZ if clock_mhz else None
     rec = {
         "value": D_total * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "scaling": wl["scaling"],
         "doc_iterations_per_s": sum_iters_total / elapsed,
@@ -384,7 +418,18 @@ def measure(job, args, name, steps, warmup, docs=None):
         # flops = 4 K sum_d I_d N_d of the inner iterations executed IN THE TIMED WINDOW (device counters)
         "roofline_fp64": {"bound": "fp64 vector FMA", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
                           "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": flops,
-                          "mean_inner_iterations": sum_iters / calls / max(1, D_local)},
+                          "mean_inner_iterations": sum_iters / calls / max(1, D_local),
+                          # algorithmic flops (4 K sum_d I_d N_d) above, so that the fraction stays comparable
+                          # with rounds 1-5; what was EXECUTED, and the clock the chip sustained, beside it
+                          "executed_flops": executed, "live_fraction": executed / flops if flops > 0 else None,
+                          "executed_achieved": executed / (doc_ms * 1e-3) / 1e12 if doc_ms > 0 else 0.0,
+                          "documents_handed_to_live_topic_kernel": handed_over / calls,
+                          "clock_mhz": clock_mhz, "peak_clock_mhz": PEAK_CLOCK_MHZ,
+                          "peak_at_clock": peak_at_clock,
+                          "frac_at_clock": tflops / peak_at_clock if peak_at_clock else None,
+                          "clock_source": "resident kernels of the timed E-steps time themselves in shader cycles "
+                                          "(s_memtime) and in ticks of the constant-rate counter (s_memrealtime): "
+                                          "pylda_clock_counters"},
         "joint_log_likelihood": joint,
         "startup": {"generate_corpus_s": t_gen, "upload_and_schedule_s": t_init,
                     "first_step_s": t_step1, "first_%d_steps_s" % PROTOCOL_WARMUP: t_first,
@@ -412,8 +457,8 @@ def cpu_leg(ctx, vb, wl, args, budget_s, max_docs, value, all_cores=0):
         "cpu_baseline": {
             "value": rate, "unit": "docs/s", "cores": 1, "kind": "port",
             "sample": "first %d documents of rank 0's corpus, numpy/scipy restatement of "
-                      "variational_bayes.py:132-216 (oracle/vb_numpy.py), single thread; "
-                      "host has %d cores" % (n, os.cpu_count()),
+                      "variational_bayes.py:132-216 (oracle/vb_numpy.py), single thread, median of 3 timings of the "
+                      "same documents; host has %d cores" % (n, os.cpu_count()),
             "c_port_docs_per_s": c_oracle_rate(alpha, eta, ptr, ids, cts, n)},
         "ll_delta": {"max_rel": float(delta.max()), "median_rel": float(np.median(delta)),
                      "docs": int(n), "bar": 1e-5},
@@ -457,7 +502,7 @@ def host_contract_leg(vb):
 XGMI_LINK_GBPS = 153.0           # one of a GPU's 7 peer links; a ring all-reduce is bound by one link
 
 
-def shard_proxy(job, args, step_ms_full):
+def shard_proxy(job, args, step_ms_full, clock_full=None):
     """Single-GPU PROXY for the strong-scaling curve of cfg 4 (no multi-GPU node is available to this run): rank 0's
     step at the shard sizes N = 2 / 4 / 8 would produce - 1M / N documents with the FULL K x V tables - measured on
     this one GPU, plus a MODEL of the exchange (bytes / xGMI link figure, not overlapped).  Shows what does not
@@ -480,8 +525,26 @@ def shard_proxy(job, args, step_ms_full):
         for _ in range(PROTOCOL_WARMUP):
             vb.learning()
         job.torch.cuda.synchronize()
+        ctx.model_checkpoint()
+        alpha_ckpt, counter_ckpt = vb._alpha_alpha.copy(), vb._counter
+
+        def restore():
+            ctx.model_checkpoint(restore=True)
+            vb._alpha_alpha = alpha_ckpt.copy()
+            vb._counter = counter_ckpt
+
+        # >= 2 s of the SAME window, untimed, before the timed one: every leg is measured at the clock the chip sustains
+        # under this load, not at what a short run catches on the way up or down (round 5's N = 8 leg timed 0.27 s after
+        # 0.16 s of warm-up and came out 5 % "super-linear"); the sustained clock of each leg is in the record
+        t_steady = time.perf_counter()
+        while time.perf_counter() - t_steady < 2.0:
+            for _ in range(PROTOCOL_WINDOW):
+                vb.learning()
+            job.torch.cuda.synchronize()
+            restore()
         ctx.set_profiling(True)
         ctx.kernel_time()
+        ctx.work_counters()
         vb._verbose = True                      # (stream marks around the E-step and M-step spans; the line itself is swallowed)
         walls, e_span, m_span = [], [], []
         for _ in range(PROTOCOL_WINDOW):
@@ -491,12 +554,14 @@ def shard_proxy(job, args, step_ms_full):
             walls.append((time.perf_counter() - t0) * 1e3)
             e_span.append(ctx.elapsed_ms(0, 1))
             m_span.append(ctx.elapsed_ms(1, 2))
+        ctx.work_counters()
+        clock_mhz = ctx.shader_clock_mhz()
         doc_ms, ss_ms, calls = ctx.kernel_time()
         ctx.set_profiling(False)
         calls = max(1, calls)
         doc_ms, ss_ms = doc_ms / calls, ss_ms / calls
         ldk = ctx_table_stride(ctx)
-        nbytes = V * K * 8                      # what crosses the links: the live K columns of the V x ldk statistics
+        nbytes = V * ldk * 8                    # what crosses the links: the V x ldk statistics pylda_allreduce_sstats reduces (csrc/comm.hip)
         ring = 2.0 * (n - 1) / n * nbytes / (XGMI_LINK_GBPS * 1e9) * 1e3
         direct = 2.0 * nbytes / n / (XGMI_LINK_GBPS * 1e9) * 1e3
         step = float(np.mean(walls))
@@ -507,7 +572,7 @@ def shard_proxy(job, args, step_ms_full):
                      "estep_span_ms": float(np.mean(e_span)), "mstep_span_ms": float(np.mean(m_span)),
                      "table_prep_ms": float(np.mean(e_span)) - doc_ms - ss_ms,
                      "host_and_launch_ms": step - float(np.mean(e_span)) - float(np.mean(m_span)),
-                     "allreduce_bytes": nbytes, "table_stride": ldk,
+                     "allreduce_bytes": nbytes, "table_stride": ldk, "clock_mhz": clock_mhz,
                      "allreduce_ms_model_ring": ring, "allreduce_ms_model_direct": direct,
                      "predicted_ms_per_step": predicted, "predicted_docs_per_s": total_docs / (predicted * 1e-3),
                      "predicted_strong_scaling_efficiency": step_ms_full / (n * predicted)})
@@ -515,9 +580,10 @@ def shard_proxy(job, args, step_ms_full):
         del vb, ctx, wl
     return {"model": True,
             "note": "NOT a multi-GPU measurement: rank 0's shard of cfg 4 for N = 2 / 4 / 8 timed on ONE GPU (full K x V "
-                    "tables, nnz-balanced document shard) + a modelled, non-overlapped ring all-reduce of the K x V "
-                    "statistics at %.0f GB/s per xGMI link; efficiency = T(1) / (N * (T_shard(N) + T_allreduce(N)))" % XGMI_LINK_GBPS,
-            "ms_per_step_n1": step_ms_full, "per_n": rows}
+                    "tables, nnz-balanced document shard; every leg after >= 2 s of the same steps, its sustained shader "
+                    "clock recorded) + a modelled, non-overlapped ring all-reduce of the V x ldk statistics at %.0f GB/s "
+                    "per xGMI link; efficiency = T(1) / (N * (T_shard(N) + T_allreduce(N)))" % XGMI_LINK_GBPS,
+            "ms_per_step_n1": step_ms_full, "ms_per_step_n1_clock_mhz": clock_full, "per_n": rows}
 
 
 def ctx_table_stride(ctx):
@@ -592,7 +658,7 @@ def main():
     extras = not args.no_extras and args.workload == "synth1m"
     if extras and job.world == 1 and not args.no_shard_proxy:
         # ---- single-GPU proxy of the strong-scaling curve: rank 0's shard of cfg 4 for N = 2 / 4 / 8 ----
-        out["shard_proxy"] = shard_proxy(job, args, rec["ms_per_step"])
+        out["shard_proxy"] = shard_proxy(job, args, rec["ms_per_step"], rec["roofline_fp64"].get("clock_mhz"))
     if extras:
         # ---- cfg 3 (100k documents per GPU, K=128) alongside, every N: weak scaling + its own roofline ----
         try:
@@ -802,7 +868,7 @@ def nips_shard_proxy(job, g, step_ms_full):
         ctx.set_profiling(False)
         calls = max(1, calls)
         num_cu = job.torch.cuda.get_device_properties(job.device).multi_processor_count
-        ring = 2.0 * (n - 1) / n * V * K * 8 / (XGMI_LINK_GBPS * 1e9) * 1e3
+        ring = 2.0 * (n - 1) / n * V * ctx_table_stride(ctx) * 8 / (XGMI_LINK_GBPS * 1e9) * 1e3      # (V x ldk: what pylda_allreduce_sstats reduces)
         rows.append({"n_gpus_modelled": n, "docs_rank0": hi, "nnz_rank0": int(ptr[hi]), "ms_per_step_measured": step,
                      "kernel_ms_documents": doc_ms / calls, "kernel_ms_sstats": ss_ms / calls,
                      "launch_classes": [(c["kernel"], c["geometry"], c["documents"]) for c in classes],

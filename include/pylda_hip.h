@@ -49,7 +49,7 @@ typedef enum pylda_status {
  *      pylda_set_stream(NULL) = HIP's null stream (pylda_use_own_stream restores the private one)
  *   3  additions only: pylda_abi_version, pylda_mstep_enqueue / pylda_outer_device / pylda_allreduce_outer /
  *      pylda_outer_fetch (one host wait per outer iteration), pylda_model_checkpoint, pylda_mark_time /
- *      pylda_elapsed_ms, pylda_work_counters, pylda_executed_work, pylda_host_alloc / pylda_host_free, pylda_test_alpha_update;
+ *      pylda_elapsed_ms, pylda_work_counters, pylda_executed_work, pylda_clock_counters, pylda_host_alloc / pylda_host_free, pylda_test_alpha_update;
  *      pylda_set_alpha no longer waits for the stream (and is a no-op when handed the values the device holds)
  * A host compiled against another version must refuse to run: compare PYLDA_ABI_VERSION with
  * pylda_abi_version() right after loading the library. */
@@ -235,12 +235,16 @@ int pylda_kernel_time(pylda_ctx* ctx, double* doc_kernel_ms, double* sstats_kern
  * actually ran (sum_d I_d) and their terms (sum_d I_d N_d: 4 K flops each, :177-185).  Returns and resets them
  * (synchronises). */
 int pylda_work_counters(pylda_ctx* ctx, double* inner_iterations, double* inner_iteration_terms);
-/* ... and what the kernels really ran (same accumulation, same reset; call it right BEHIND pylda_work_counters - the two
- * share one read of the device counters): tile_entries = sum_d N_d (K x iterations of the dense kernel + tile columns x
- * iterations of the live-topic kernel) - two FMAs each - and the documents handed to the live-topic kernel
- * (estep_compact.h: the iterations of :174-190 on the topics whose gamma still differs from alpha).
- * tile_entries / (K x inner_iteration_terms) is the fraction of the dense N_d x K work that was executed. */
+/* ... and the rest of the SAME read (no device access: the values of the last pylda_work_counters call):
+ * what the kernels really ran - tile_entries = sum_d N_d (K x iterations of the dense kernel + tile columns x iterations
+ * of the live-topic kernel), two FMAs each, and the documents handed to the live-topic kernel (estep_compact.h: the
+ * iterations of :174-190 on the topics whose gamma still differs from alpha); tile_entries / (K x inner_iteration_terms)
+ * is the fraction of the dense N_d x K work that was executed - */
 int pylda_executed_work(pylda_ctx* ctx, double* tile_entries, double* handed_over);
+/* ... and the shader clock under that load: spans of resident kernels of the profiled E-steps (one in 64 live-topic
+ * wavefronts, the work counter's own kernel) measured twice - in shader cycles (s_memtime) and in ticks of the constant
+ * wall_hz counter (s_memrealtime).  Sustained clock in Hz = shader_ticks / wall_ticks * wall_hz. */
+int pylda_clock_counters(pylda_ctx* ctx, double* shader_ticks, double* wall_ticks, double* wall_hz);
 
 /* The launch schedule of a corpus: documents are bucketed by distinct-term
  * count into launch classes (one kernel instantiation each; the classes of one
@@ -257,7 +261,8 @@ int pylda_corpus_plan(pylda_corpus* corpus, int32_t capacity, int32_t* variant, 
  * statistics gather (1: unblocked; set when the first training E-step builds the postings, 0 before),
  * "gather_segments" - its posting segments, "gather_rounds" - the term ranges the gather is run in so that their
  * segments share one set of partial rows, "gather_partial_rows" - those rows, "gather_sweep_passes" - passes of the
- * persistent sweep that replaces rows and rounds (0: not in use).  Returns the value, or a negative pylda_status. */
+ * persistent sweep that replaces rows and rounds (0: not in use), "gather_live" - 1: the pass reads the documents' lists of
+ * live topics (sstats_live.h).  Returns the value, or a negative pylda_status. */
 int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
 
 /* Tuning / test options:
@@ -298,6 +303,12 @@ int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
  *   "launch_order"   1 (default): launch classes with the fewest documents go out first, 0: longest documents first
  *                    (scheduling options never change a bit of the results);
  *   "slab_uber"      1 (default): the slab launch classes of a small corpus go out as one dispatch;
+ *   "gather_live"    1 (default): where a corpus hands documents to the live-topic kernel ("compact") the statistics pass
+ *                    reads the lists of live topics those documents leave (10 bytes per live topic instead of a row of K
+ *                    doubles per posting; one plain walk of the postings: no document blocks, sweep or rounds); 0: the
+ *                    row gathers above.  Takes effect for corpora whose postings are built afterwards;
+ *   "compact_phase"  1 (default): the live-topic kernels of an E-step run behind ALL its dense kernels, 0: behind their
+ *                    launch class on its stream (scheduling only);
  *   "compact"        1 (default): at 64 < K <= 256 a document leaves the dense kernel once few enough topics still move
  *                    (gamma_k != alpha_k bitwise; 20-32 by document length) and finishes on the live-topic kernel; 0: dense
  *                    kernels only.  Same iteration counts, results equal to rounding (another summation order);

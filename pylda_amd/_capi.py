@@ -71,6 +71,7 @@ SIGNATURES = {
     "pylda_elapsed_ms": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _c_double_p]),
     "pylda_work_counters": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
     "pylda_executed_work": (ctypes.c_int, [_vp, _c_double_p, _c_double_p]),
+    "pylda_clock_counters": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p]),
     "pylda_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pylda_kernel_time": (ctypes.c_int, [_vp, _c_double_p, _c_double_p, _c_int64_p]),
     "pylda_corpus_layout": (ctypes.c_int64, [_vp, ctypes.c_char_p]),
@@ -452,11 +453,18 @@ class Context(object):
         return a.value, b.value
 
     def executed_work(self):
-        """(tile entries the kernels ran through the FMA pipes, documents handed to the live-topic kernel) of the same
-        E-steps: call right behind work_counters() (one read of the device counters serves both)."""
+        """(tile entries the kernels ran through the FMA pipes, documents handed to the live-topic kernel) of the E-steps
+        the LAST work_counters() call read (no device access)."""
         a, b = ctypes.c_double(0), ctypes.c_double(0)
         self._check(self._lib.pylda_executed_work(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def shader_clock_mhz(self):
+        """Sustained shader clock under the load of the E-steps the last work_counters() call read, or None (no span was
+        sampled): resident kernels time themselves in shader cycles and in ticks of the constant-rate counter."""
+        a, b, hz = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.pylda_clock_counters(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(hz)))
+        return a.value / b.value * hz.value / 1e6 if b.value > 0 else None
 
     # ---- device-resident interop ----
     def sstats_elements(self):

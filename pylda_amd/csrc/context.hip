@@ -133,8 +133,8 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     CREATE_TRY(dev_alloc(ctx, &ctx->d_partial, (size_t)1024 * K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_outer, (size_t)(3 * K + 8)));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_newton_work, (size_t)4 * K));
-    CREATE_TRY(dev_alloc(ctx, &ctx->d_work, (size_t)4));
-    CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_work, 0, 4 * sizeof(double), ctx->stream), "hipMemsetAsync"));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_work, (size_t)6));
+    CREATE_TRY(hip_ok(hipMemsetAsync(ctx->d_work, 0, 6 * sizeof(double), ctx->stream), "hipMemsetAsync"));
     CREATE_TRY(hip_ok(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), (size_t)(5 * K + 8) * sizeof(double), hipHostMallocDefault),
                       "hipHostMalloc"));
     for (int i = 0; i < 2; ++i)
@@ -427,24 +427,14 @@ int pylda_elapsed_ms(pylda_ctx* ctx, int slot_from, int slot_to, double* ms)
     return PYLDA_OK;
 }
 
-namespace {
-// the four work counters of the profiled E-steps since the last read (doc_terms.h work_count_kernel), read and reset
-int fetch_work(pylda_ctx* ctx)
+int pylda_work_counters(pylda_ctx* ctx, double* inner_iterations, double* inner_iteration_terms)
 {
+    if (!ctx) return PYLDA_ERR_INVALID;
+    // ONE read (and reset) of the device counters; pylda_executed_work / pylda_clock_counters report the rest of it
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->work_cache, ctx->d_work, sizeof ctx->work_cache, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof ctx->work_cache, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PYLDA_OK;
-}
-}  // namespace
-
-int pylda_work_counters(pylda_ctx* ctx, double* inner_iterations, double* inner_iteration_terms)
-{
-    if (!ctx) return PYLDA_ERR_INVALID;
-    const int rc = fetch_work(ctx);
-    if (rc != PYLDA_OK) return rc;
-    ctx->work_cached = true;            // (pylda_executed_work reports the other half of this read)
     if (inner_iterations) *inner_iterations = ctx->work_cache[0];
     if (inner_iteration_terms) *inner_iteration_terms = ctx->work_cache[1];
     return PYLDA_OK;
@@ -453,13 +443,21 @@ int pylda_work_counters(pylda_ctx* ctx, double* inner_iterations, double* inner_
 int pylda_executed_work(pylda_ctx* ctx, double* tile_entries, double* handed_over)
 {
     if (!ctx) return PYLDA_ERR_INVALID;
-    if (!ctx->work_cached) {            // not behind pylda_work_counters: a read (and reset) of its own
-        const int rc = fetch_work(ctx);
-        if (rc != PYLDA_OK) return rc;
-    }
-    ctx->work_cached = false;
     if (tile_entries) *tile_entries = ctx->work_cache[2];
     if (handed_over) *handed_over = ctx->work_cache[3];
+    return PYLDA_OK;
+}
+
+int pylda_clock_counters(pylda_ctx* ctx, double* shader_ticks, double* wall_ticks, double* wall_hz)
+{
+    if (!ctx) return PYLDA_ERR_INVALID;
+    if (shader_ticks) *shader_ticks = ctx->work_cache[4];
+    if (wall_ticks) *wall_ticks = ctx->work_cache[5];
+    if (wall_hz) {
+        int khz = 0;
+        HIP_TRY(ctx, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+        *wall_hz = 1e3 * khz;
+    }
     return PYLDA_OK;
 }
 

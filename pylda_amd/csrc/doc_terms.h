@@ -65,13 +65,15 @@ __global__ __launch_bounds__(256) void doc_terms_kernel(EstepParams p, int64_t c
 
 // Profiling: work[0] += sum_d I_d, work[1] += sum_d I_d N_d (inner iterations executed, and their terms), work[2] +=
 // sum_d N_d (K x dense iterations + tile columns x live-topic iterations) (the tile entries the kernels really ran
-// through the FMA pipes, twice per iteration), work[3] += documents handed to the live-topic kernel - single workgroup,
-// so the accumulation over E-steps needs no atomics.
+// through the FMA pipes, twice per iteration), work[3] += documents handed to the live-topic kernel, work[4 .. 5] += this
+// kernel's span in shader cycles and in ticks of the constant-rate counter (the live-topic kernel adds samples of its
+// own) - single workgroup, so the accumulation over E-steps needs no atomics.
 __global__ __launch_bounds__(1024) void work_count_kernel(const int32_t* __restrict__ iters, const int64_t* __restrict__ doc_ptr,
                                                           int64_t D, double* __restrict__ work, const int32_t* __restrict__ handoff_it,
                                                           const int32_t* __restrict__ col_iters, int K)
 {
     __shared__ double scratch[16];
+    const long long tick0 = clock64(), wall0 = wall_clock64();          // work[4], work[5]: this kernel's own span in both clocks
     double a = 0.0, b = 0.0, e = 0.0, h = 0.0;
     for (int64_t d = threadIdx.x; d < D; d += 1024) {
         const double it = (double)iters[d], n = (double)(doc_ptr[d + 1] - doc_ptr[d]);
@@ -94,6 +96,8 @@ __global__ __launch_bounds__(1024) void work_count_kernel(const int32_t* __restr
         work[1] += b;
         work[2] += e;
         work[3] += h;
+        work[4] += (double)(clock64() - tick0);
+        work[5] += (double)(wall_clock64() - wall0);
     }
 }
 

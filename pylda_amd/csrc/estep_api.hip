@@ -269,6 +269,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     p.tile_ptr = c->d_tile_ptr;
     p.handoff_it = c->d_handoff_it;
     p.col_iters = c->d_col_iters;
+    p.clock_acc = ctx->profiling ? ctx->d_work + 4 : nullptr;
     p.alpha_max = *std::max_element(ctx->h_alpha.begin(), ctx->h_alpha.end());
     p.alpha_min = ctx->compact_guard_fail ? 0.0 : *std::min_element(ctx->h_alpha.begin(), ctx->h_alpha.end());
     if (c->compact_ready) {

@@ -52,6 +52,7 @@ struct EstepParams {
     double alpha_max, alpha_min;   // over the K topics (the exactness guard of the live-topic kernel)
     int32_t* handoff_it;      // D out: inner iterations the dense kernel ran before it handed the document over (else left at -1)
     int32_t* col_iters;       // D out: sum over the live-topic kernel's iterations of the tile columns it ran them on
+    double* clock_acc;        // profiling (else NULL): [shader-clock ticks, constant-rate ticks] of sampled kernel spans, accumulated
 };
 
 constexpr int kLiveStride = 32;   // entries per document's list: the largest live set the live-topic kernel takes over

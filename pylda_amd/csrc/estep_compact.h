@@ -32,6 +32,7 @@
 #pragma once
 #include "estep_common.h"
 #include "special_device.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace pylda {
 
@@ -330,6 +331,16 @@ __global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
     const int lane = threadIdx.x;
     const int doc = p.order[blockIdx.x];
     if (p.status[doc] != 4) return;
+    // one wavefront in 64 times itself twice - shader cycles and the constant-rate counter: the sustained clock under
+    // this load (pylda_clock_counters)
+    const bool timed = p.clock_acc != nullptr && (blockIdx.x & 63) == 0;
+    const long long tick0 = timed ? clock64() : 0, wall0 = timed ? wall_clock64() : 0;
+    auto clock_out = [&]() {
+        if (timed && lane == 0) {
+            unsafeAtomicAdd(p.clock_acc, (double)(clock64() - tick0));
+            unsafeAtomicAdd(p.clock_acc + 1, (double)(wall_clock64() - wall0));
+        }
+    };
     const int K = p.K, ldk = p.ldk;
     const int64_t lo = p.doc_ptr[doc];
     const int N = (int)(p.doc_ptr[doc + 1] - lo);
@@ -407,6 +418,7 @@ __global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
             }
         }
         if (lane == 0) p.status[doc] = 1;
+        clock_out();
         return;
     }
 
@@ -445,6 +457,7 @@ __global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
             p.iters[doc] = st.it;
             p.status[doc] = 3;
         }
+        clock_out();
         return;
     }
 
@@ -497,6 +510,7 @@ __global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
         p.iters[doc] = st.it;
         p.status[doc] = 0;
     }
+    clock_out();
 }
 
 }  // namespace pylda

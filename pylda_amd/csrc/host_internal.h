@@ -87,9 +87,9 @@ struct pylda_ctx {
     NewtonParams newton;
     double* d_newton_work = nullptr;   // 4 K
     double* d_eta_ckpt = nullptr;   // pylda_model_checkpoint
-    double* d_work = nullptr;       // profiling: [sum_d I_d, sum_d I_d N_d, tile entries executed, documents handed over] accumulated over E-steps
-    double work_cache[4] = {0.0, 0.0, 0.0, 0.0};   // one read of d_work serves pylda_work_counters and pylda_executed_work
-    bool work_cached = false;
+    double* d_work = nullptr;       // profiling, accumulated over E-steps: [sum_d I_d, sum_d I_d N_d, tile entries executed, documents handed
+                                    // over, shader-clock ticks, constant-rate ticks of the same spans]
+    double work_cache[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // the last read of d_work (pylda_work_counters)
     hipEvent_t mark_event[4] = {nullptr, nullptr, nullptr, nullptr};
     void* comm = nullptr;           // RCCL communicator of pylda_comm_init (multi-GPU through the C ABI)
     int comm_world = 1;

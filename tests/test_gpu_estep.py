@@ -484,6 +484,7 @@ def test_document_blocked_statistics_gather(capi, ap_train, K, blocks, rows):
     out = {}
     for nb in (0, blocks):
         ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_live", 0)                 # (the row gathers; the pass over the live lists: test_statistics_from_live_lists)
         ctx.set_option("gather_rows", rows)
         ctx.set_option("gather_blocks", nb)
         corpus = ctx.corpus(ptr, tid, tct)
@@ -516,6 +517,7 @@ def test_statistics_gather_in_rounds(capi, ap_train, K, blocks):
     got = {}
     for budget in (0, 1):
         ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_live", 0)
         ctx.set_option("gather_sweep", 0)
         ctx.set_option("gather_blocks", blocks)
         ctx.set_option("gather_round_mb", budget)
@@ -549,6 +551,7 @@ def test_statistics_gather_as_a_persistent_sweep(capi, ap_train, K, blocks, wide
     got = {}
     for sweep in (0, 1, 1):
         ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_live", 0)
         ctx.set_option("gather_sweep", 2 * sweep)            # (2: whatever the size of the partial rows)
         ctx.set_option("gather_blocks", blocks)
         ctx.set_option("wide_postings", wide)
@@ -575,6 +578,7 @@ def test_statistics_gather_as_a_persistent_sweep(capi, ap_train, K, blocks, wide
                     [("gather_sweep", 2), ("sweep_sub", 1)], [("gather_sweep", 2), ("sweep_sub", 7)],     # sub-steps of a block
                     [("terms_overlap", 0), ("launch_order", 0), ("gather_sweep", 2), ("sweep_xcd", 0)]):
         ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_live", 0)
         ctx.set_option("gather_blocks", blocks)
         ctx.set_option("wide_postings", wide)
         for name, value in options:
@@ -589,6 +593,49 @@ def test_statistics_gather_as_a_persistent_sweep(capi, ap_train, K, blocks, wide
         assert np.array_equal(ctx.get_sstats(), want[0]) and fast == want[1], options
         corpus.close()
         ctx.close()
+
+
+@pytest.mark.parametrize("K,wide", [(128, 0), (256, 0), (200, 1), (100, 0)])
+def test_statistics_from_live_lists(capi, ap_train, K, wide):
+    """sstats_live.h: a document the live-topic kernel finished leaves a list of its live topics and their t instead of
+    a row of t; the statistics pass adds r t per list entry into LDS accumulators, one wavefront per posting segment.
+    With alpha = 1 / K most topics of a document die (gamma_k == alpha_k bitwise): against the row gather of the same
+    E-step, the oracle, bitwise repeatable, 64-bit posting positions; documents without a list (the dense kernels
+    finished them) are mixed in."""
+    from oracle import c_oracle
+    g = ap_train
+    rng = np.random.default_rng(5 * K + wide)
+    ptr = g["doc_ptr"][:701]
+    tid, tct = g["term_id"][:ptr[-1]], g["term_ct"][:ptr[-1]]
+    eta = rng.gamma(100.0, 0.01, (K, 6806))
+    eta[:, rng.permutation(6806)[:3000]] *= rng.uniform(0.01, 30.0, (K, 3000))       # topics with a vocabulary of their own
+    alpha = np.full(K, 1.0 / K)
+    got = {}
+    for live in (0, 1, 1):
+        ctx = capi.Context(K, 6806)
+        ctx.set_option("gather_live", live)
+        ctx.set_option("wide_postings", wide)
+        corpus = ctx.corpus(ptr, tid, tct)
+        res = ctx.estep_host(corpus, alpha, eta)
+        assert corpus.layout("gather_live") == live
+        ctx.set_option("doc_values", 0)
+        ctx.set_profiling(True)
+        ctx.work_counters()
+        ctx.estep(corpus)
+        fast = ctx.estep_results(corpus)[0]
+        ctx.work_counters()
+        handed = ctx.executed_work()[1]
+        assert abs(fast - res["document_log_likelihood"]) < 1e-11 * abs(res["document_log_likelihood"])
+        got.setdefault(live, []).append((res["sstats"], fast, res["iters"], handed))
+        corpus.close()
+        ctx.close()
+    ref = c_oracle.e_step(alpha, eta, ptr, tid, tct)
+    assert 0 < got[1][0][3] <= 700, "documents must have been handed to the live-topic kernel"
+    assert np.array_equal(got[1][0][2], ref["iters"])
+    assert np.max(np.abs(got[1][0][0] - got[0][0][0])) < 1e-11
+    assert np.max(np.abs(got[1][0][0] - ref["sstats"])) < SSTATS_ATOL
+    assert abs(got[1][0][0].sum() - tct.sum()) < 1e-7
+    assert np.array_equal(got[1][0][0], got[1][1][0]) and got[1][0][1] == got[1][1][1]
 
 
 def test_runs_on_the_system_hip_runtime_without_torch():

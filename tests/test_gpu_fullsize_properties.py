@@ -79,6 +79,42 @@ def test_fast_path_and_reproducibility_at_full_size(cfg3):
     ctx.set_option("doc_values", 1)
 
 
+def test_live_topic_kernel_against_the_dense_kernels_at_full_size(cfg3):
+    """on the FULL cfg 3 / cfg 4 corpora the E-step with the hand-over to the live-topic kernel
+    (estep_compact.h, the default the fixture ran) and the dense kernels alone (option compact = 0) execute the same
+    number of inner iterations for EVERY document; gamma, the per-document log-likelihoods and the statistics agree
+    to rounding - another summation order inside normalisers and topic sums, not another result.  The counts of
+    entries that differ at all are printed."""
+    c, ctx, corpus = cfg3, cfg3["ctx"], cfg3["corpus"]
+    ctx.set_profiling(True)
+    ctx.work_counters()
+    ctx.estep(corpus)                                     # (the fixture's E-step again, for the work counters)
+    its, terms = ctx.work_counters()
+    entries, handed = ctx.executed_work()
+    ctx.set_profiling(False)
+    assert handed > 0.99 * c["D"], "nearly every document goes to the live-topic kernel: %d of %d" % (handed, c["D"])
+    live_fraction = entries / (c["K"] * terms)
+    ctx.set_option("compact", 0)
+    ctx.estep(corpus)
+    ll, _, nlog = ctx.estep_results(corpus)
+    doc_ll, _, iters = ctx.get_doc_values(corpus)
+    gamma = ctx.get_gamma(corpus)
+    sstats = ctx.get_sstats()
+    ctx.set_option("compact", 1)
+    flips = int((iters != c["iters"]).sum())
+    differing = int((gamma != c["gamma"]).sum())
+    g_rel = float(np.max(np.abs(gamma - c["gamma"]) / gamma))
+    ll_rel = float(np.max(np.abs(doc_ll - c["doc_ll"]) / np.abs(doc_ll)))
+    ss_abs = float(np.max(np.abs(sstats - c["sstats"])))
+    print("%s: live-topic vs dense kernels: %d iteration-count flips in %d documents; %d of %d gamma entries differ, max rel %.2e; "
+          "per-document log-likelihood max rel %.2e; statistics max abs %.2e; executed fraction of the dense tile work %.3f"
+          % (c["name"], flips, c["D"], differing, gamma.size, g_rel, ll_rel, ss_abs, live_fraction))
+    assert nlog == 0 and flips == 0
+    assert g_rel < 1e-9 and ll_rel < 1e-11 and ss_abs < 1e-9
+    assert abs(ll - c["ll"]) < 1e-13 * abs(c["ll"])
+    assert live_fraction < 0.75
+
+
 def test_shard_additivity_at_full_size(cfg3):
     """Document sharding (the multi-GPU decomposition): statistics of the shards add up to the whole."""
     from pylda_amd.corpus import shard_csr

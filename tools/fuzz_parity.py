@@ -28,7 +28,8 @@ def sweep(budget=60.0, seed=0, verbose=True):
         eta = rng.gamma(100.0, 0.01, (K, V))
         if rng.random() < 0.5:
             eta[:, rng.choice(V, V // 3, replace=False)] = 1.0 / V
-        alpha = rng.uniform(0.02, 1.5, K) if rng.random() < 0.7 else np.full(K, float(rng.choice([0.005, 0.05, 1.0 / K])))
+        # (small alpha: topics die - gamma_k == alpha_k bitwise - and documents go to the live-topic kernel)
+        alpha = rng.uniform(0.02, 1.5, K) if rng.random() < 0.5 else np.full(K, float(rng.choice([0.005, 0.05, 1.0 / K, 1.0 / K, 0.5 / K])))
         tol = float(rng.choice([1e-6, 1e-6, 1e-4, 1e-8]))
         ref = c_oracle.e_step(alpha, eta, ptr, ids, cts, 50, tol)
         ctx = _capi.Context(K, V)
@@ -37,6 +38,10 @@ def sweep(budget=60.0, seed=0, verbose=True):
         ctx.set_option("gather_sweep", int(rng.choice([0, 1, 2, 2])))               # persistent sweep where the gather is blocked
         ctx.set_option("gather_round_mb", int(rng.choice([0, 0, 1])))               # ... or rounds over term ranges
         ctx.set_option("slab_uber", int(rng.choice([0, 1, 1])))
+        ctx.set_option("compact", int(rng.choice([0, 1, 1, 1])))                    # hand-over to the live-topic kernel (64 < K <= 256) ...
+        ctx.set_option("compact_cap", int(rng.choice([0, 0, 8, 12, 17])))           # ... at its capacity, or earlier shapes of it
+        ctx.set_option("compact_phase", int(rng.choice([0, 1])))
+        ctx.set_option("gather_live", int(rng.choice([0, 1, 1])))                   # statistics from the lists of live topics
         ctx.set_option("wide_postings", int(rng.choice([0, 0, 1])))
         corpus = ctx.corpus(ptr, ids, cts)
         out = ctx.estep_host(corpus, alpha, eta, 50, tol, False)
