@@ -309,10 +309,14 @@ int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
  *                    row gathers above.  Takes effect for corpora whose postings are built afterwards;
  *   "compact_phase"  1 (default): the live-topic kernels of an E-step run behind ALL its dense kernels, 0: behind their
  *                    launch class on its stream (scheduling only);
- *   "compact"        1 (default): at 64 < K <= 256 a document leaves the dense kernel once few enough topics still move
- *                    (gamma_k != alpha_k bitwise; 20-32 by document length) and finishes on the live-topic kernel; 0: dense
- *                    kernels only.  Same iteration counts, results equal to rounding (another summation order);
- *   "compact_cap"    test hook: hand over at this many live topics at most (0: the kernel's capacity; <= 32);
+ *   "compact"        1 (default): at 64 < K <= 512 a document leaves the dense kernel once few enough topics still move
+ *                    (gamma_k != alpha_k bitwise; 8-64 by document length and table stride) and finishes on the live-topic
+ *                    kernel; 0: dense kernels only.  Same iteration counts, results equal to rounding (another summation order);
+ *   "compact_pair"   -1 (default): from table stride 256 on a document is handed over at twice the columns one wavefront
+ *                    holds and starts on two wavefronts that split the columns; 0: never, 1: always;
+ *   "compact_stream" 1 (default): the fused streaming kernel (table stride 384 / 512) hands over too - without a tile, the
+ *                    live-topic kernel gathers its entries from the table; 0: the quad kernel only;
+ *   "compact_cap"    test hook: hand over at this many live topics at most (0: the kernel's capacity; <= 64);
  *   "compact_guard_fail" test hook: the live-topic kernel's exactness guard fails for every document (they are redone by
  *                    the log-space kernel);
  *   "quad" (1: documents of <= 224 distinct terms at 64 < K <= 256 run on the quad kernel), "quad_stream" (1: ... and

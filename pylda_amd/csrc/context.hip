@@ -253,6 +253,10 @@ int pylda_set_option(pylda_ctx* ctx, const char* name, int64_t value)
         ctx->gather_live = value != 0;
     } else if (!strcmp(name, "compact")) {
         ctx->compact = value != 0;
+    } else if (!strcmp(name, "compact_pair")) {
+        ctx->compact_pair = value < 0 ? -1 : value != 0;
+    } else if (!strcmp(name, "compact_stream")) {
+        ctx->compact_stream = value != 0;
     } else if (!strcmp(name, "compact_phase")) {
         ctx->compact_phase = value != 0;
     } else if (!strcmp(name, "compact_cap")) {

@@ -261,7 +261,9 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
                 break;
             }
     // hand-over to the live-topic kernel: its buffers, and the per-document work counters of this E-step
-    p.handoff_live = 0;
+    p.handoff_on = 0;
+    p.tile_from_table = 0;
+    compact_caps(ctx, p.handoff_caps);
     p.live_n = c->d_live_n;
     p.live_list = c->d_live_list;
     p.live_stats = (!heldout && c->live_stats) ? 1 : 0;
@@ -327,11 +329,11 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             p.order = c->d_order + L.first;
             p.n_cap = L.n_cap;
             p.tile_stride = L.tile_stride;
-            p.handoff_live = c->compact_ready ? compact_handoff_for(ctx, L) : 0;
+            p.handoff_on = c->compact_ready && compact_handoff_for(ctx, L) > 0 ? 1 : 0;
             const int class_bracket = open_bracket(slot, ctx->stream);
             if (getenv("PYLDA_DEBUG_SYNC"))
                 fprintf(stderr, "[pylda debug] launching class %d variant %d geometry %d documents %lld n_cap %d handoff %d\n", slot, L.variant, L.rn,
-                        (long long)L.count, L.n_cap, p.handoff_live);
+                        (long long)L.count, L.n_cap, p.handoff_on);
             switch (L.variant) {
             case kSlab: rc = launch_slab_any(ctx, p, L); break;
             case kQuilt: rc = launch_quilt_any(ctx, p, L); break;
@@ -345,12 +347,14 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             if (debug_sync) {
                 const hipError_t e = hipStreamSynchronize(ctx->stream);
                 fprintf(stderr, "[pylda debug] class %d variant %d geometry %d documents %lld handoff %d: %s\n", slot, L.variant, L.rn,
-                        (long long)L.count, p.handoff_live, hipGetErrorString(e));
+                        (long long)L.count, p.handoff_on, hipGetErrorString(e));
             }
             // ... and behind it, on the same stream, the live-topic kernel for the documents the class handed over
             // (option compact_phase 0; the default runs them as a phase of their own behind all dense kernels, below)
-            if (rc == PYLDA_OK && p.handoff_live > 0 && !ctx->compact_phase) rc = launch_compact(ctx, p, L);
-            if (debug_sync && p.handoff_live > 0 && !ctx->compact_phase) {
+            if (p.handoff_on && !ctx->compact_phase)
+                for (const pylda_corpus::CompactRange& r : c->compact_ranges)
+                    if (rc == PYLDA_OK && r.plan_index == slot) rc = launch_compact(ctx, c, p, r.slots, r.from_table, r.first, r.count);
+            if (debug_sync && p.handoff_on && !ctx->compact_phase) {
                 const hipError_t e = hipStreamSynchronize(ctx->stream);
                 fprintf(stderr, "[pylda debug] class %d live-topic kernel: %s\n", slot, hipGetErrorString(e));
             }
@@ -361,7 +365,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             }
         }
         ctx->stream = main_stream;
-        p.handoff_live = 0;
+        p.handoff_on = 0;
         if (uber_from >= 0) {
             const Launch& L = c->plan[(size_t)uber_from];
             p.order = c->d_order + L.first;
@@ -383,28 +387,19 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         // the two never meet.  One launch per lane shape (term slots per lane): the classes of a shape are contiguous in
         // the schedule.
         if (c->compact_ready && ctx->compact_phase) {
-            Launch group[5];
-            for (Launch& g : group) g.count = 0;
-            for (const Launch& L : c->plan) {
-                if (compact_handoff_for(ctx, L) <= 0) continue;
-                Launch& g = group[std::min(4, std::max(1, (L.n_cap + kWave - 1) / kWave))];
-                if (g.count == 0) {
-                    g = L;
-                } else {
-                    const int64_t lo = std::min(g.first, L.first), hi = std::max(g.first + g.count, L.first + L.count);
-                    g.first = lo;
-                    g.count = hi - lo;
-                    g.n_cap = std::max(g.n_cap, L.n_cap);
+            // one launch per lane shape (term slots per lane): the ranges of a shape are adjacent across the classes
+            for (size_t a = 0; a < c->compact_ranges.size();) {
+                const pylda_corpus::CompactRange& r = c->compact_ranges[a];
+                int64_t count = r.count;
+                size_t b = a + 1;
+                while (b < c->compact_ranges.size() && c->compact_ranges[b].slots == r.slots && c->compact_ranges[b].from_table == r.from_table &&
+                       c->compact_ranges[b].first == r.first + count) {
+                    count += c->compact_ranges[b].count;
+                    ++b;
                 }
+                if ((rc = launch_compact(ctx, c, p, r.slots, r.from_table, r.first, count)) != PYLDA_OK) return rc;
+                a = b;
             }
-            for (const Launch& g : group) {
-                if (g.count == 0) continue;
-                p.order = c->d_order + g.first;
-                p.n_cap = g.n_cap;
-                p.handoff_live = compact_handoff_for(ctx, g);
-                if ((rc = launch_compact(ctx, p, g)) != PYLDA_OK) return rc;
-            }
-            p.handoff_live = 0;
         }
     }
     // the document terms the register kernels left out on the training fast path (status 3; doc_terms.h): one wavefront

@@ -41,8 +41,11 @@ struct EstepParams {
     int n_cap;                // max distinct terms of any document in this launch
     int tile_stride;          // LDS row stride in doubles (odd)
     double* term_scratch;     // nnz scratch doubles, only for documents too long for the LDS (estep_generic.h MODE 2)
-    // ---- hand-over to the live-topic kernel (estep_compact.h); handoff_live == 0: never ----
-    int handoff_live;         // a document leaves the dense kernel once at most this many topics have gamma_k != alpha_k
+    // ---- hand-over to the live-topic kernel (estep_compact.h) ----
+    int handoff_on;           // 1: a document of N terms leaves the dense kernel once at most handoff_caps[ceil(N / 64)] topics have
+    int handoff_caps[9];      //    gamma_k != alpha_k (0: never) - the columns the live-topic kernel's register tile holds at that many
+                              //    term slots per lane
+    int tile_from_table;      // live-topic kernel: 1: the launch's documents have no tile in live_tile - gather it from the table
     int32_t* live_n;          // D: live topics of a document handed over (status 4); after the E-step: entries of its list of t
                               //    (live_stats), -1: the document's t is the dense row tfinal[d]
     char* live_list;          // D x kLiveListBytes: topic indices (uint16 x kLiveStride), then t of the last iteration (double x kLiveStride)
@@ -55,8 +58,16 @@ struct EstepParams {
     double* clock_acc;        // profiling (else NULL): [shader-clock ticks, constant-rate ticks] of sampled kernel spans, accumulated
 };
 
-constexpr int kLiveStride = 32;   // entries per document's list: the largest live set the live-topic kernel takes over
-// A document's list: [uint16 topic x 32][double t x 32] - the indices and the first eight t share the first 128 bytes
+// the live-topic count at which a document of N terms leaves a dense kernel (-1: never)
+__device__ __forceinline__ int handoff_threshold(const EstepParams& p, int N)
+{
+    const int slots = (N + kWave - 1) / kWave;
+    const int cap = p.handoff_on && slots <= 8 ? p.handoff_caps[slots > 0 ? slots : 1] : 0;
+    return cap > 0 ? cap : -1;
+}
+
+constexpr int kLiveStride = 64;   // entries per document's list: the largest live set the live-topic kernel takes over (two wavefronts x 32 columns)
+// A document's list: [uint16 topic x 64][double t x 64], 640 bytes: a document of <= 16 live topics touches two 128-byte lines
 constexpr int kLiveListBytes = kLiveStride * 2 + kLiveStride * 8;
 __device__ __forceinline__ uint16_t* live_idx_of(char* live_list, int64_t doc) { return reinterpret_cast<uint16_t*>(live_list + doc * kLiveListBytes); }
 __device__ __forceinline__ double* live_t_of(char* live_list, int64_t doc)

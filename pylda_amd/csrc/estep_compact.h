@@ -122,7 +122,7 @@ __device__ __forceinline__ double compact_reduce_from(const double (&x)[R], int 
     }
 }
 
-// ---- LDS of a wavefront: the hand-over state between bodies, and the epilogue's row of t ----
+// ---- LDS of a document's workgroup: the hand-over state between bodies, and the epilogue's row of t ----
 struct CompactLds {
     double gam[kLiveStride];        // gamma of the live topics (column order)
     double gprev[kLiveStride];      // ... before the last update
@@ -143,19 +143,100 @@ struct CompactState {
 
 enum CompactExit { kCompactDone = 0, kCompactShrink = 1 };
 
-// The inner loop on an S x LT register tile.  Returns when the document is finished (stop test, iteration cap) or when
-// at most `shrink_to` columns are still alive (0: never) - st.L, lds.idx / col / gam are then the surviving ones.
+// Where a lane's tile values come from: the columns the dense quad kernel wrote (live_tile, term-minor), or - documents of
+// the streaming kernels, which keep no tile on chip to write - the table itself (N x L scattered reads, once per body).
+template <int S>
+struct CompactSource {
+    const double* tile;     // the document's columns, or nullptr
+    const double* table;    // expElog
+    int ldk, N;
+    int wid[S];             // table mode: term ids of this lane's slots (-1 beyond the document)
+    __device__ __forceinline__ double value(int s, int lane, int column, int topic) const
+    {
+        const int n = s * kWave + lane;
+        if (n >= N) return 1.0;                                           // a slot beyond the document: ones, count 0
+        return tile ? tile[(size_t)column * N + n] : table[(size_t)wid[s] * ldk + topic];
+    }
+};
+
+// this lane's column after the reduce-scatter of LT values (the recursion of compact_column_of on the lane's bits, shape
+// constants folded), or -1; `first`: the replica with the lowest lane number
+template <int LT>
+__device__ __forceinline__ int compact_my_column(int lane, bool* first_replica)
+{
+    int m = 0;
+    bool valid = true, first = true;
+    static_for<6>([&](auto idx) {
+        constexpr int k = 5 - decltype(idx)::value;
+        constexpr int rr = compact_count_at(LT, k), half = compact_half(rr);
+        const bool bit = ((lane >> (5 - k)) & 1) != 0;
+        if constexpr (rr == 1) {
+            if (bit) first = false;
+        } else {
+            if (bit) {
+                m += half;
+                if (m >= rr) valid = false;
+            }
+        }
+    });
+    *first_replica = first;
+    return valid ? m : -1;
+}
+
+// q_j = sum_s r_s C[s][j] per lane, then over the 64 lanes: the value of this lane's column
+template <int S, int LT>
+__device__ __forceinline__ double compact_topic_sums(const double (&C)[S][LT], const double (&r)[S], int lane)
+{
+    constexpr int H0 = (LT + 1) / 2;
+    double y0[H0];
+#pragma unroll
+    for (int m = 0; m < H0; ++m) {
+        double qa = r[0] * C[0][m], qb = m + H0 < LT ? r[0] * C[0][m + H0 < LT ? m + H0 : 0] : 0.0;
+#pragma unroll
+        for (int s = 1; s < S; ++s) {
+            qa = fma(r[s], C[s][m], qa);
+            if (m + H0 < LT) qb = fma(r[s], C[s][m + H0 < LT ? m + H0 : 0], qb);
+        }
+        y0[m] = swap32_add(qa, qb);
+    }
+    return compact_reduce_from<1, H0>(y0, lane);
+}
+
+// The columns still alive move up, in order (lane j < L looks after column j); a column that died keeps alpha_k for good.
+// One wavefront; the state of all columns is in LDS.
+__device__ __forceinline__ void compact_keep_alive(const EstepParams& p, int doc, CompactLds& lds, CompactState& st)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool mine = lane < st.L;
+    const int at = mine ? lane : 0;
+    const double g = lds.gam[at], a = lds.alf[at];
+    const int topic = lds.idx[at], column = lds.col[at];
+    const bool alive = mine && g != a;
+    const unsigned long long mask = __ballot(alive);
+    if (mine && !alive) p.gamma[(size_t)doc * p.K + topic] = g;
+    wave_lds_exchange();
+    if (alive) {
+        const int to = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        lds.gam[to] = g;
+        lds.alf[to] = a;
+        lds.idx[to] = topic;
+        lds.col[to] = column;
+    }
+    wave_lds_exchange();
+    st.L = __builtin_popcountll(mask);
+}
+
+// The inner loop on an S x LT register tile, ONE wavefront.  Returns when the document is finished (stop test, iteration
+// cap) or when at most `shrink_to` columns are still alive (0: never) - st.L, lds.idx / col / gam are then the survivors.
 template <int S, int LT>
 __device__ __forceinline__ int compact_body(const EstepParams& p, int doc, int64_t lo, int N, double psi_total, double thresh_f,
-                                            CompactLds& lds, CompactState& st, int shrink_to, double (&r)[S])
+                                            CompactLds& lds, CompactState& st, int shrink_to, const CompactSource<S>& src, double (&r)[S])
 {
     static_assert(LT >= 4 && LT <= kLiveStride && LT % 4 == 0, "columns of the register tile");
     const int lane = threadIdx.x & (kWave - 1);
     const int L = st.L;
-    const double* tile = p.live_tile + p.tile_ptr[doc];
 
-    // the tile: C[s][j] = value of term lane + 64 s, column j.  A term slot beyond the document: ones (its normaliser is
-    // sum_j t_j > 0, its count 0); a column beyond L: zeros (t_j = 0 as well)
+    // the tile: C[s][j] = value of term lane + 64 s, column j; a column beyond L: zeros (t_j = 0 as well)
     double C[S][LT];
     double cnt[S];
 #pragma unroll
@@ -165,38 +246,16 @@ __device__ __forceinline__ int compact_body(const EstepParams& p, int doc, int64
     }
 #pragma unroll
     for (int j = 0; j < LT; ++j) {
-        const int cj = __builtin_amdgcn_readfirstlane(j < L ? lds.col[j < kLiveStride ? j : 0] : 0);
-        const double* column = tile + (size_t)cj * N;
+        const int at = j < L ? j : 0;
+        const int cj = __builtin_amdgcn_readfirstlane(lds.col[at]), topic = __builtin_amdgcn_readfirstlane(lds.idx[at]);
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int n = s * kWave + lane;
-            C[s][j] = j < L ? (n < N ? column[n] : 1.0) : 0.0;
-        }
+        for (int s = 0; s < S; ++s) C[s][j] = j < L ? src.value(s, lane, cj, topic) : 0.0;
     }
 
-    // this lane's column in the gamma phase (the recursion of compact_column_of on the lane's bits, shape constants folded)
-    bool primary = false;
-    int mycol = -1;
-    {
-        int m = 0;
-        bool valid = true, first = true;
-        static_for<6>([&](auto idx) {
-            constexpr int k = 5 - decltype(idx)::value;
-            constexpr int rr = compact_count_at(LT, k), half = compact_half(rr);
-            const bool bit = ((lane >> (5 - k)) & 1) != 0;
-            if constexpr (rr == 1) {
-                if (bit) first = false;
-            } else {
-                if (bit) {
-                    m += half;
-                    if (m >= rr) valid = false;
-                }
-            }
-        });
-        mycol = valid && m < L ? m : -1;
-        primary = mycol >= 0 && first;
-    }
-    const bool owns = mycol >= 0;
+    bool first_replica = false;
+    int mycol = compact_my_column<LT>(lane, &first_replica);
+    if (mycol >= L) mycol = -1;
+    const bool owns = mycol >= 0, primary = owns && first_replica;
     double gam = owns ? lds.gam[owns ? mycol : 0] : 1.0;
     const double alpha_k = owns ? lds.alf[owns ? mycol : 0] : 1.0;
     double t;
@@ -243,19 +302,7 @@ __device__ __forceinline__ int compact_body(const EstepParams& p, int doc, int64
         coef_a.load();
         coef_b.load();
         // B. topic sums: per lane over its terms, then over the lanes                 :185
-        constexpr int H0 = (LT + 1) / 2;
-        double y0[H0];
-#pragma unroll
-        for (int m = 0; m < H0; ++m) {
-            double qa = r[0] * C[0][m], qb = m + H0 < LT ? r[0] * C[0][m + H0 < LT ? m + H0 : 0] : 0.0;
-#pragma unroll
-            for (int s = 1; s < S; ++s) {
-                qa = fma(r[s], C[s][m], qa);
-                if (m + H0 < LT) qb = fma(r[s], C[s][m + H0 < LT ? m + H0 : 0], qb);
-            }
-            y0[m] = swap32_add(qa, qb);
-        }
-        const double q = compact_reduce_from<1, H0>(y0, lane);
+        const double q = compact_topic_sums<S, LT>(C, r, lane);
         // C. gamma update on the lanes that own a column                               :185-188
         const double gnew = fma(t, q, alpha_k);
         const double diff = fabs(gnew - gam);
@@ -286,28 +333,147 @@ __device__ __forceinline__ int compact_body(const EstepParams& p, int doc, int64
         lds.tlast[mycol] = tused;
     }
     wave_lds_exchange();
-    if (exit_code == kCompactShrink) {
-        // the columns still alive move up, in order: lane j < L looks after column j
-        const bool mine = lane < L;
-        const int at = mine ? lane : 0;
-        const double g = lds.gam[at], a = lds.alf[at];
-        const int topic = lds.idx[at], column = lds.col[at];
-        const bool alive = mine && g != a;
-        const unsigned long long mask = __ballot(alive);
-        // a column that died here: its gamma is alpha_k for good
-        if (mine && !alive) p.gamma[(size_t)doc * p.K + topic] = g;
-        wave_lds_exchange();
-        if (alive) {
-            const int to = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            lds.gam[to] = g;
-            lds.alf[to] = a;
-            lds.idx[to] = topic;
-            lds.col[to] = column;
-        }
-        wave_lds_exchange();
-        st.L = __builtin_popcountll(mask);
-    }
+    if (exit_code == kCompactShrink) compact_keep_alive(p, doc, lds, st);
     st.cols += (it - st.it) * LT;
+    st.it = it;
+    st.left = left;
+    st.bad = bad;
+    st.nrm_min = nrm_min;
+    st.r_max = r_max;
+    return exit_code;
+}
+
+// The same loop on TWO wavefronts that split the COLUMNS (wavefront w owns columns 2 m + w, m < TPW): twice the register
+// tile - documents of up to 2 TPW live topics, i.e. the dense kernel lets go five iterations earlier, and documents whose
+// live set never falls to one wavefront's capacity (a trained model: 20-35 topics per document) leave it at all.
+// Per iteration the wavefronts exchange ONE thing, their partial normalisers (S doubles per lane through LDS, one
+// barrier): both then hold the same normalisers and r, bit for bit (the sum is wave 0's part + wave 1's part on both),
+// and everything else - topic sums, gamma, t, the stop sum - is local to the columns a wavefront owns.  The stop sum and
+// the live count of an iteration travel with the NEXT iteration's partials: the decision to stop is taken one exchange
+// late, and the partial normalisers computed in between are dropped.  Returns like compact_body; with kCompactShrink
+// (at most `hand_down_to` columns alive) the caller lets wavefront 1 go and wavefront 0 carries on alone.
+template <int S, int TPW>
+__device__ __forceinline__ int compact_pair_body(const EstepParams& p, int doc, int64_t lo, int N, double psi_total, double thresh_f,
+                                                 CompactLds& lds, double* xchg, CompactState& st, int hand_down_to, const CompactSource<S>& src,
+                                                 double (&r)[S])
+{
+    static_assert(TPW >= 4 && 2 * TPW <= kLiveStride && TPW % 4 == 0, "columns of a wavefront's register tile");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int L = st.L;
+    double* xn = xchg;                                      // [2][2][S][64] partial normalisers
+    double* xs = xchg + 2 * 2 * S * kWave;                  // [2][2][2]     stop sum, live columns
+
+    double C[S][TPW];
+    double cnt[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int n = s * kWave + lane;
+        cnt[s] = n < N ? (double)p.term_ct[lo + n] : 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < TPW; ++m) {
+        const int j = 2 * m + wave, at = j < L ? j : 0;
+        const int cj = __builtin_amdgcn_readfirstlane(lds.col[at]), topic = __builtin_amdgcn_readfirstlane(lds.idx[at]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) C[s][m] = j < L ? src.value(s, lane, cj, topic) : 0.0;
+    }
+    bool first_replica = false;
+    const int mine_local = compact_my_column<TPW>(lane, &first_replica);
+    int mycol = mine_local >= 0 ? 2 * mine_local + wave : -1;
+    if (mycol >= L) mycol = -1;
+    const bool owns = mycol >= 0, primary = owns && first_replica;
+    double gam = owns ? lds.gam[owns ? mycol : 0] : 1.0;
+    const double alpha_k = owns ? lds.alf[owns ? mycol : 0] : 1.0;
+    double t;
+    {
+        ExpDigammaLevelsA coef_a;
+        coef_a.load();
+        t = exp_digamma_minus_levels(gam, psi_total, coef_a);
+        if (!owns) t = 0.0;
+    }
+    double gprev = gam, tused = t;
+    int it = st.it, left = st.left, bad = st.bad;
+    double nrm_min = st.nrm_min, r_max = st.r_max;
+    double moved_mine = 0.0;
+    int alive_mine = 0;
+    int exit_code = kCompactDone;
+
+    for (bool first = true;; first = false) {                                 // :174
+        double ts[TPW];
+        static_for<TPW>([&](auto idx) {
+            constexpr int m = decltype(idx)::value;
+            constexpr int from = compact_lane_of(TPW, m);
+            static_assert(from >= 0 && from < kWave, "every column has a lane");
+            ts[m] = readlane_f64(t, from);
+        });
+        // A. this wavefront's part of the normalisers, out to the other one - with the stop sum and the live columns of
+        //    the iteration before
+        double pn[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) pn[s] = C[s][0] * ts[0];
+#pragma unroll
+        for (int m = 1; m < TPW; ++m)
+#pragma unroll
+            for (int s = 0; s < S; ++s) pn[s] = fma(C[s][m], ts[m], pn[s]);
+        const int buf = it & 1;
+#pragma unroll
+        for (int s = 0; s < S; ++s) xn[((buf * 2 + wave) * S + s) * kWave + lane] = pn[s];
+        if (lane == 0) {
+            xs[(buf * 2 + wave) * 2] = moved_mine;
+            xs[(buf * 2 + wave) * 2 + 1] = (double)alive_mine;
+        }
+        lds_only_barrier();
+        double nrm[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const double other = xn[((buf * 2 + (wave ^ 1)) * S + s) * kWave + lane];
+            nrm[s] = wave == 0 ? pn[s] + other : other + pn[s];               // (wave 0's part + wave 1's part, on both)
+        }
+        if (!first) {
+            const double moved = xs[(buf * 2 + 0) * 2] + xs[(buf * 2 + 1) * 2];
+            const int alive = (int)(xs[(buf * 2 + 0) * 2 + 1] + xs[(buf * 2 + 1) * 2 + 1]);
+            if (uniform_f64(moved) <= thresh_f || left <= 0) break;           // :189, :174
+            if (__builtin_amdgcn_readfirstlane(alive) <= hand_down_to) {
+                exit_code = kCompactShrink;
+                break;
+            }
+        }
+        tused = t;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (cnt[s] > 0.0 && !(nrm[s] > 1e-280)) bad = 1;
+            r[s] = cnt[s] * rcp_newton(nrm[s]);
+            nrm_min = fmin(nrm_min, nrm[s]);
+            r_max = fmax(r_max, r[s]);
+        }
+        ExpDigammaLevelsA coef_a;
+        ExpDigammaLevelsB coef_b;
+        coef_a.load();
+        coef_b.load();
+        // B. topic sums of the columns this wavefront owns                                :185
+        const double q = compact_topic_sums<S, TPW>(C, r, lane);
+        // C. their gamma update                                                           :185-188
+        const double gnew = fma(t, q, alpha_k);
+        const double diff = fabs(gnew - gam);
+        gprev = gam;
+        gam = gnew;
+        const double moved = primary ? __builtin_rint(fmin(diff, 1024.0) * kChangeScale) : 0.0;
+        t = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
+        if (!owns) t = 0.0;
+        moved_mine = wave_sum(moved);
+        alive_mine = __builtin_popcountll(__ballot(primary && gam != alpha_k));
+        ++it;
+        --left;
+    }
+
+    // state to LDS, both wavefronts; the caller's barrier publishes it
+    if (primary) {
+        lds.gam[mycol] = gam;
+        lds.gprev[mycol] = gprev;
+        lds.tlast[mycol] = tused;
+    }
+    st.cols += (it - st.it) * 2 * TPW;
     st.it = it;
     st.left = left;
     st.bad = bad;
@@ -318,22 +484,28 @@ __device__ __forceinline__ int compact_body(const EstepParams& p, int doc, int64
 
 __device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
 
-constexpr size_t compact_lds_bytes(int ldk) { return ((sizeof(CompactLds) + 15) & ~(size_t)15) + (size_t)ldk * 8; }
+// LDS of a workgroup: the state, the pair body's exchange area, the epilogue's row of t (row mode of the statistics only)
+constexpr size_t compact_state_bytes() { return (sizeof(CompactLds) + 15) & ~(size_t)15; }
+constexpr size_t compact_xchg_bytes(int slots, int tpw) { return tpw > 0 ? (size_t)(2 * 2 * slots * kWave + 8) * 8 : 0; }
+constexpr size_t compact_lds_bytes(int ldk, int slots, int tpw) { return compact_state_bytes() + compact_xchg_bytes(slots, tpw) + (size_t)ldk * 8; }
 
-// One wavefront per document of the launch class; S = term slots per lane (N <= 64 S).  Documents the dense kernel
-// finished itself (status != 4) are skipped.
-template <int S, int LTMAX>
-__global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
+// One workgroup per document of the launch; S = term slots per lane (N <= 64 S); LTMAX: columns one wavefront holds;
+// TPW > 0: the workgroup is TWO wavefronts that hold TPW columns each while more than LTMAX are alive (compact_pair_body),
+// then wavefront 1 leaves.  Documents the dense kernel finished itself (status != 4) are skipped.
+template <int S, int LTMAX, int TPW>
+__global__ __launch_bounds__(TPW > 0 ? 2 * kWave : kWave, 2) void estep_compact_kernel(EstepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CompactLds& lds = *reinterpret_cast<CompactLds*>(smem);
-    double* trow = reinterpret_cast<double*>(smem + ((sizeof(CompactLds) + 15) & ~(size_t)15));     // [ldk]
-    const int lane = threadIdx.x;
+    double* xchg = reinterpret_cast<double*>(smem + compact_state_bytes());
+    double* trow = reinterpret_cast<double*>(smem + compact_state_bytes() + compact_xchg_bytes(S, TPW));     // [ldk]
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int doc = p.order[blockIdx.x];
     if (p.status[doc] != 4) return;
-    // one wavefront in 64 times itself twice - shader cycles and the constant-rate counter: the sustained clock under
+    // one workgroup in 64 times itself twice - shader cycles and the constant-rate counter: the sustained clock under
     // this load (pylda_clock_counters)
-    const bool timed = p.clock_acc != nullptr && (blockIdx.x & 63) == 0;
+    const bool timed = p.clock_acc != nullptr && (blockIdx.x & 63) == 0 && wave == 0;
     const long long tick0 = timed ? clock64() : 0, wall0 = timed ? wall_clock64() : 0;
     auto clock_out = [&]() {
         if (timed && lane == 0) {
@@ -346,7 +518,7 @@ __global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
     const int N = (int)(p.doc_ptr[doc + 1] - lo);
     const int L0 = p.live_n[doc];
 
-    if (lane < L0) {
+    if (wave == 0 && lane < L0) {
         const int topic = live_idx_of(p.live_list, doc)[lane];
         lds.idx[lane] = topic;
         lds.col[lane] = lane;
@@ -362,7 +534,15 @@ __global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
     asum = wave_sum(asum);
     const double psi_total = uniform_f64(digamma(asum + total));
     const double thresh_f = p.tol * K * kChangeScale;
-    wave_lds_exchange();
+    CompactSource<S> src;
+    src.tile = p.tile_from_table ? nullptr : p.live_tile + p.tile_ptr[doc];
+    src.table = p.expElog;
+    src.ldk = ldk;
+    src.N = N;
+#pragma unroll
+    for (int s = 0; s < S; ++s) src.wid[s] = p.tile_from_table && s * kWave + lane < N ? p.term_id[lo + s * kWave + lane] : 0;
+    if constexpr (TPW > 0) lds_only_barrier();
+    else wave_lds_exchange();
 
     CompactState st;
     st.L = L0;
@@ -373,30 +553,44 @@ __global__ __launch_bounds__(kWave, 2) void estep_compact_kernel(EstepParams p)
     st.nrm_min = 1e300;
     st.r_max = 0.0;
     double r[S];
-    for (;;) {
+    bool finished = false;
+    if constexpr (TPW > 0) {
+        if (st.L > LTMAX) {
+            const int code = compact_pair_body<S, TPW>(p, doc, lo, N, psi_total, thresh_f, lds, xchg, st, LTMAX, src, r);
+            lds_only_barrier();                             // both wavefronts' columns are in LDS
+            if (wave != 0) return;
+            finished = code == kCompactDone;
+            if (!finished) compact_keep_alive(p, doc, lds, st);
+        } else if (wave != 0) {
+            return;
+        }
+    }
+    while (!finished) {
         int code;
         // the smallest instantiation that holds the live columns; it runs until the next smaller one would do
         if constexpr (LTMAX > 24) {
             if (st.L > 24) {
-                code = compact_body<S, LTMAX>(p, doc, lo, N, psi_total, thresh_f, lds, st, 24, r);
-                if (code == kCompactDone) break;
+                code = compact_body<S, LTMAX>(p, doc, lo, N, psi_total, thresh_f, lds, st, 24, src, r);
+                finished = code == kCompactDone;
                 continue;
             }
         }
         if constexpr (LTMAX > 16) {
             if (st.L > 16) {
-                code = compact_body<S, (LTMAX < 24 ? LTMAX : 24)>(p, doc, lo, N, psi_total, thresh_f, lds, st, 16, r);
-                if (code == kCompactDone) break;
+                code = compact_body<S, (LTMAX < 24 ? LTMAX : 24)>(p, doc, lo, N, psi_total, thresh_f, lds, st, 16, src, r);
+                finished = code == kCompactDone;
                 continue;
             }
         }
-        if (st.L > 8) {
-            code = compact_body<S, 16>(p, doc, lo, N, psi_total, thresh_f, lds, st, 8, r);
-            if (code == kCompactDone) break;
-            continue;
+        if constexpr (LTMAX > 8) {
+            if (st.L > 8) {
+                code = compact_body<S, (LTMAX < 16 ? LTMAX : 16)>(p, doc, lo, N, psi_total, thresh_f, lds, st, 8, src, r);
+                finished = code == kCompactDone;
+                continue;
+            }
         }
-        code = compact_body<S, 8>(p, doc, lo, N, psi_total, thresh_f, lds, st, 0, r);
-        break;
+        code = compact_body<S, 8>(p, doc, lo, N, psi_total, thresh_f, lds, st, 0, src, r);
+        finished = true;
     }
     const int L = st.L;
 

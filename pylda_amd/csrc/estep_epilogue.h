@@ -79,4 +79,30 @@ __device__ __forceinline__ void finish_document(const EstepParams& p, int doc, i
     }
 }
 
+// Hand-over of a document from a STREAMING dense kernel (estep_qfuse.h, estep_qfusek.h) to the live-topic kernel
+// (estep_compact.h): gamma after `it` updates and the live topics in ascending order - no tile, these kernels keep none
+// on chip (the live-topic kernel gathers its N x L entries from the table).  Thread tid owns topic tid (tid < padded K);
+// `counts`: one unsigned per wavefront of the workgroup in LDS.  Every thread of the workgroup calls it.
+__device__ __forceinline__ void stream_hand_over(const EstepParams& p, int doc, int tid, bool topic_live, double gam, double alpha_k, unsigned* counts,
+                                                 int waves, int it)
+{
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    const bool alive = topic_live && gam != alpha_k;
+    const unsigned long long mask = __ballot(alive);
+    if (lane == 0) counts[wave] = (unsigned)__builtin_popcountll(mask);
+    __syncthreads();
+    int at = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) at += (int)counts[w];
+    if (alive) live_idx_of(p.live_list, doc)[at] = (uint16_t)tid;
+    if (topic_live) p.gamma[(size_t)doc * p.K + tid] = gam;
+    if (tid == 0) {
+        unsigned total = 0;
+        for (int w = 0; w < waves; ++w) total += counts[w];
+        p.live_n[doc] = (int)total;
+        p.handoff_it[doc] = it;
+        p.iters[doc] = it;
+        p.status[doc] = 4;
+    }
+}
+
 }  // namespace pylda

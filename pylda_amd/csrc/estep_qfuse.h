@@ -182,7 +182,15 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     const bool topic_live = tid < K;
     if (topic_thread) alf[tid] = topic_live ? p.alpha[tid] : 1.0;
     if (c == 0) misc[wave] = local;
-    if (tid == 0) chg[0] = chg[1] = 0ull;
+    // live topics after an iteration (gamma_k != alpha_k bitwise), for the hand-over to the live-topic kernel; and the
+    // per-wavefront counts of that exit - both in the idle part of misc
+    unsigned* livec = reinterpret_cast<unsigned*>(misc + 2 * W);
+    unsigned* wcount = reinterpret_cast<unsigned*>(misc + 3 * W);
+    if (tid == 0) {
+        chg[0] = chg[1] = 0ull;
+        livec[0] = livec[1] = 0u;
+    }
+    const int handoff_at = handoff_threshold(p, N);
     __syncthreads();                                        // also: myoff / mycnt are in place
 
     // ---- on-chip tiers: registers, LDS rows ----
@@ -347,14 +355,26 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
             gpv[tid] = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
+            {
+                const unsigned long long moving = __ballot(topic_live && gnew != alpha_k);
+                if (c == 0) atomicAdd(&livec[buf], (unsigned)__builtin_popcountll(moving));
+            }
             const double t_next = exp_digamma_minus_levels(gam, psi_total)   /* (tables fetched in place: no scalar registers to spare across pass B) */;
             tt[(buf ^ 1) * KT + tid] = topic_live ? t_next : 0.0;
-            if (tid == 0) store_u64_hi(&chg[buf ^ 1], 0u);
+            if (tid == 0) {
+                store_u64_hi(&chg[buf ^ 1], 0u);
+                livec[buf ^ 1] = 0u;
+            }
         }
         ++it;
         __syncthreads();
         const double change = (double)chg[buf] * (1.0 / kChangeScale);
         if (change <= p.tol * K) break;                                   // :189 (mean <= tol)
+        // few enough topics still move: the live-topic kernel (estep_compact.h) runs the remaining iterations on them
+        if (it < p.max_iter && __builtin_amdgcn_readfirstlane((int)livec[buf]) <= handoff_at && !__syncthreads_or(bad)) {
+            stream_hand_over(p, doc, tid, topic_live, gam, alf[tid < KT ? tid : 0], wcount, W, it);
+            return;
+        }
     }
     const int last = (it - 1) & 1;
 

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     // topics whose gamma differs from alpha (bitwise) after the last update, and the count at which the document
     // leaves this kernel (-1: never)
     int nlive = KT;
-    const int handoff_at = p.handoff_live > 0 ? p.handoff_live : -1;
+    const int handoff_at = handoff_threshold(p, N);
     double tq[KRL];
 #pragma unroll
     for (int jj = 0; jj < KRL / 2; ++jj) {

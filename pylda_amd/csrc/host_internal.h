@@ -120,6 +120,8 @@ struct pylda_ctx {
     int compact = 1;                // the dense quad kernel hands a document to the live-topic kernel (estep_compact.h) once few topics move
     int gather_live = 1;            // the statistics pass reads the documents' lists of live topics (sstats_live.h) where the corpus hands documents over
     int compact_phase = 1;          // the live-topic kernels run behind ALL dense kernels of the E-step (0: behind their class, on its stream)
+    int compact_stream = 1;         // ... and so do the fused streaming kernels (384 <= table stride <= 1024), without a tile
+    int compact_pair = -1;          // hand over at twice one wavefront's columns (two-wavefront body): -1 from table stride 256 on, 0 never, 1 always
     int compact_cap = 0;            // test hook: hand over at this many live topics at most (0: what the class' register tile holds)
     int compact_guard_fail = 0;     // test hook: the live-topic kernel's exactness guard fails for every document
     int plan_epoch = 0;
@@ -195,7 +197,10 @@ struct pylda_corpus {
     int32_t* d_col_iters = nullptr;       // D: tile columns x iterations the live-topic kernel executed
     bool compact_ready = false;
     bool compact_failed = false;          // the tile buffer did not fit: dense kernels only, for good
-    int compact_plan_epoch = -1, compact_cap_used = -1;
+    int compact_plan_epoch = -1, compact_cap_used = -1, compact_stream_used = -1, compact_pair_used = -2;
+    // schedule ranges of one lane shape (term slots per lane) inside a launch class that hands documents over
+    struct CompactRange { int plan_index, slots; bool from_table; int64_t first, count; };
+    std::vector<CompactRange> compact_ranges;
     std::vector<Launch> plan;
     int plan_epoch = 0;
     bool plan_exact = false;       // the plan avoids the kernels with the fixed-point stop test
@@ -262,9 +267,10 @@ int launch_qfusek(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_qgroup(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 
 // ---- launch_compact.hip: the live-topic kernel behind a quad launch class ----
-int compact_handoff_for(const pylda_ctx* ctx, const Launch& L);      // live topics at which the class hands over (0: never)
-int prepare_compact(pylda_ctx* ctx, pylda_corpus* c);                // buffers of the hand-over (sets c->compact_ready)
-int launch_compact(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
+int compact_handoff_for(const pylda_ctx* ctx, const Launch& L);      // 0: the class keeps its documents, 1: hands over with tile columns, 2: without
+void compact_caps(const pylda_ctx* ctx, int (&caps)[9]);             // live topics at which a document of s term slots per lane is handed over
+int prepare_compact(pylda_ctx* ctx, pylda_corpus* c);                // buffers and ranges of the hand-over (sets c->compact_ready)
+int launch_compact(pylda_ctx* ctx, const pylda_corpus* c, EstepParams p, int slots, bool from_table, int64_t first, int64_t count);
 
 // ---- sstats_gather.hip ----
 int build_postings(pylda_corpus* c);

@@ -7,29 +7,52 @@ namespace pylda_host {
 
 namespace {
 
-// Term slots per lane and the columns the register tile of that shape holds (2 S LT VGPRs of 256, two wavefronts
-// per SIMD): the live-topic count at which a launch class hands its documents over.
-int slots_for(int n_cap) { return std::max(1, (n_cap + kWave - 1) / kWave); }
-int columns_for(int slots) { return slots <= 2 ? 32 : slots == 3 ? 28 : slots == 4 ? 20 : 0; }
+// Term slots per lane of a document of n terms, and the columns ONE wavefront's register tile holds at that shape
+// (2 S LT VGPRs of 256, two wavefronts per SIMD).  While more are alive the document's workgroup is two wavefronts
+// with that many columns each (compact_pair_body): a dense kernel hands a document over at twice the figure.
+int slots_for(int n) { return std::max(1, (n + kWave - 1) / kWave); }
+int columns_for(int slots)
+{
+    static const int columns[9] = {0, 32, 32, 28, 20, 16, 12, 8, 8};
+    return slots <= 8 ? columns[slots] : 0;
+}
 
 template <int S, int LTMAX>
-int launch_compact_as(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+int launch_compact_as(pylda_ctx* ctx, const EstepParams& p, int64_t count)
 {
-    auto kern = estep_compact_kernel<S, LTMAX>;
-    const size_t lds = compact_lds_bytes(p.ldk);
-    hipLaunchKernelGGL(kern, dim3((unsigned)L.count), dim3(kWave), lds, ctx->stream, p);
+    auto kern = estep_compact_kernel<S, LTMAX, LTMAX>;
+    const size_t lds = compact_lds_bytes(p.ldk, S, LTMAX);
+    if (lds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(2 * kWave), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PYLDA_OK;
 }
 
 }  // namespace
 
+// does the launch class hand documents to the live-topic kernel, and how: 1 with their tile columns (the quad kernel holds the
+// tile on chip), 2 without (the fused streaming kernels: the live-topic kernel gathers its tile from the table), 0 not at all
 int compact_handoff_for(const pylda_ctx* ctx, const Launch& L)
 {
-    if (L.variant != kQuad) return 0;
-    int cap = columns_for(slots_for(L.n_cap));
-    if (ctx->compact_cap > 0) cap = std::min(cap, ctx->compact_cap);
-    return cap;
+    if (L.variant == kQuad) return 1;
+    if (L.variant == kQfuse && ctx->compact_stream) return 2;      // (estep_qfusek.h, 512 < K <= 1024, keeps its documents: two topics per thread)
+    return 0;
+}
+
+void compact_caps(const pylda_ctx* ctx, int (&caps)[9])
+{
+    caps[0] = 0;
+    // Two wavefronts (twice the columns) from table stride 256 on.  At stride 128 the dense kernel runs two documents per
+    // CU and an iteration of it costs less than one of the pair body with its barrier (measured, cfg 3: document kernels
+    // 12.4 ms handing over at one wavefront's columns, 13.0 ms at twice as many); at stride 256 the two break even in
+    // the bench's window (cfg 4, 200k documents: 39.7 ms either way) and the pair is what keeps documents with 20-40 live
+    // topics - a trained model - out of the dense kernel at all.  Option compact_pair: 0 never, 1 always.
+    const bool pair = ctx->compact_pair < 0 ? ctx->ldk >= 256 : ctx->compact_pair != 0;
+    for (int slots = 1; slots <= 8; ++slots) {
+        caps[slots] = (pair ? 2 : 1) * columns_for(slots);
+        if (ctx->compact_cap > 0) caps[slots] = std::min(caps[slots], ctx->compact_cap);
+    }
 }
 
 int prepare_compact(pylda_ctx* ctx, pylda_corpus* c)
@@ -39,19 +62,34 @@ int prepare_compact(pylda_ctx* ctx, pylda_corpus* c)
     bool any = false;
     for (const Launch& L : c->plan) any = any || compact_handoff_for(ctx, L) > 0;
     if (!any) return PYLDA_OK;
-    if (c->d_live_tile && c->compact_plan_epoch == c->plan_epoch && c->compact_cap_used == ctx->compact_cap) {
+    if (c->d_live_tile && c->compact_plan_epoch == c->plan_epoch && c->compact_cap_used == ctx->compact_cap && c->compact_stream_used == ctx->compact_stream &&
+        c->compact_pair_used == ctx->compact_pair) {
         c->compact_ready = true;
         return PYLDA_OK;
     }
-    // a document's tile: N_d x (columns of its class), at an offset of its own
-    std::vector<int64_t> tile_ptr((size_t)c->D, 0);
+    // a document's tile (quad classes): N_d x (live topics it is handed over at), at an offset of its own; and the
+    // schedule ranges per lane shape (the schedule is sorted by length: the documents of a shape are contiguous in a class)
+    std::vector<int64_t> tile_ptr((size_t)c->D, -1);
+    int caps[9];
+    compact_caps(ctx, caps);
     int64_t total = 0;
-    for (const Launch& L : c->plan) {
-        const int cap = compact_handoff_for(ctx, L);
-        if (cap <= 0) continue;
-        for (int64_t i = L.first; i < L.first + L.count; ++i) {
-            tile_ptr[(size_t)c->h_order[(size_t)i]] = total;
-            total += (int64_t)c->h_terms_sorted[(size_t)i] * cap;
+    c->compact_ranges.clear();
+    for (size_t li = 0; li < c->plan.size(); ++li) {
+        const Launch& L = c->plan[li];
+        const int mode = compact_handoff_for(ctx, L);
+        if (mode == 0) continue;
+        for (int64_t i = L.first; i < L.first + L.count;) {
+            const int slots = slots_for(c->h_terms_sorted[(size_t)i]);
+            int64_t j = i;
+            while (j < L.first + L.count && slots_for(c->h_terms_sorted[(size_t)j]) == slots) {
+                if (mode == 1 && slots <= 8) {
+                    tile_ptr[(size_t)c->h_order[(size_t)j]] = total;
+                    total += (int64_t)c->h_terms_sorted[(size_t)j] * caps[slots];
+                }
+                ++j;
+            }
+            if (slots <= 8 && caps[slots] > 0) c->compact_ranges.push_back(pylda_corpus::CompactRange{(int)li, slots, mode == 2, i, j - i});
+            i = j;
         }
     }
     dev_free(c->d_live_tile);
@@ -76,19 +114,28 @@ int prepare_compact(pylda_ctx* ctx, pylda_corpus* c)
     HIP_TRY(ctx, hipMemcpy(c->d_tile_ptr, tile_ptr.data(), (size_t)c->D * sizeof(int64_t), hipMemcpyHostToDevice));
     c->compact_plan_epoch = c->plan_epoch;
     c->compact_cap_used = ctx->compact_cap;
+    c->compact_stream_used = ctx->compact_stream;
+    c->compact_pair_used = ctx->compact_pair;
     c->compact_ready = true;
     return PYLDA_OK;
 }
 
-int launch_compact(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+// the live-topic kernel over `count` schedule slots from `first` on, all of `slots` term slots per lane
+int launch_compact(pylda_ctx* ctx, const pylda_corpus* c, EstepParams p, int slots, bool from_table, int64_t first, int64_t count)
 {
-    switch (slots_for(L.n_cap)) {
-    case 1: return launch_compact_as<1, 32>(ctx, p, L);
-    case 2: return launch_compact_as<2, 32>(ctx, p, L);
-    case 3: return launch_compact_as<3, 28>(ctx, p, L);
-    case 4: return launch_compact_as<4, 20>(ctx, p, L);
+    p.order = c->d_order + first;
+    p.tile_from_table = from_table ? 1 : 0;
+    switch (slots) {
+    case 1: return launch_compact_as<1, 32>(ctx, p, count);
+    case 2: return launch_compact_as<2, 32>(ctx, p, count);
+    case 3: return launch_compact_as<3, 28>(ctx, p, count);
+    case 4: return launch_compact_as<4, 20>(ctx, p, count);
+    case 5: return launch_compact_as<5, 16>(ctx, p, count);
+    case 6: return launch_compact_as<6, 12>(ctx, p, count);
+    case 7: return launch_compact_as<7, 8>(ctx, p, count);
+    case 8: return launch_compact_as<8, 8>(ctx, p, count);
     }
-    return fail(ctx, PYLDA_ERR_STATE, "no live-topic kernel for documents of %d terms", L.n_cap);
+    return fail(ctx, PYLDA_ERR_STATE, "no live-topic kernel for %d term slots per lane", slots);
 }
 
 }  // namespace pylda_host
