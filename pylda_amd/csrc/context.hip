@@ -129,6 +129,7 @@ int pylda_create(int device, int K, int V, pylda_ctx** out)
     CREATE_TRY(dev_alloc(ctx, &ctx->d_psi_rowsum, (size_t)K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_topic_lse, (size_t)K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_alpha, (size_t)K));
+    CREATE_TRY(dev_alloc(ctx, &ctx->d_alpha_sgn, (size_t)K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_small, (size_t)(4 * K + 16)));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_partial, (size_t)1024 * K));
     CREATE_TRY(dev_alloc(ctx, &ctx->d_outer, (size_t)(3 * K + 8)));
@@ -157,7 +158,7 @@ void pylda_destroy(pylda_ctx* ctx)
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     dev_free(ctx->d_eta); dev_free(ctx->d_elog); dev_free(ctx->d_expElog); dev_free(ctx->d_expElog_elog); dev_free(ctx->d_sstats);
     dev_free(ctx->d_kv_scratch); dev_free(ctx->d_shift); dev_free(ctx->d_beta);
-    dev_free(ctx->d_psi_rowsum); dev_free(ctx->d_topic_lse); dev_free(ctx->d_alpha);
+    dev_free(ctx->d_psi_rowsum); dev_free(ctx->d_topic_lse); dev_free(ctx->d_alpha); dev_free(ctx->d_alpha_sgn);
     dev_free(ctx->d_small); dev_free(ctx->d_partial); dev_free(ctx->d_outer); dev_free(ctx->d_newton_work); dev_free(ctx->d_work); dev_free(ctx->d_eta_ckpt);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (int i = 0; i < 2; ++i)

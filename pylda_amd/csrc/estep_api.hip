@@ -230,6 +230,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     p.shift = ctx->d_shift;
     p.topic_lse = ctx->d_topic_lse;
     p.alpha = ctx->d_alpha;
+    p.alpha_sgn = ctx->d_alpha;       // (no document is handed over: every topic is its plain alpha)
     double asum = 0.0, alg = 0.0;
     for (double a : ctx->h_alpha) {
         asum += a;
@@ -262,6 +263,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             }
     // hand-over to the live-topic kernel: its buffers, and the per-document work counters of this E-step
     p.handoff_on = 0;
+    p.handoff_live = 0;
     p.tile_from_table = 0;
     compact_caps(ctx, p.handoff_caps);
     p.live_n = c->d_live_n;
@@ -272,9 +274,11 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
     p.handoff_it = c->d_handoff_it;
     p.col_iters = c->d_col_iters;
     p.clock_acc = ctx->profiling ? ctx->d_work + 4 : nullptr;
-    p.alpha_max = *std::max_element(ctx->h_alpha.begin(), ctx->h_alpha.end());
     p.alpha_min = ctx->compact_guard_fail ? 0.0 : *std::min_element(ctx->h_alpha.begin(), ctx->h_alpha.end());
     if (c->compact_ready) {
+        // which topics may count as dead at all (kMortalT): alpha with a sign bit, for the kernels that hand documents over
+        hipLaunchKernelGGL(alpha_mortality_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->d_alpha, K, ctx->d_alpha_sgn);
+        p.alpha_sgn = ctx->d_alpha_sgn;
         HIP_TRY(ctx, hipMemsetAsync(c->d_handoff_it, 0xff, (size_t)c->D * sizeof(int32_t), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(c->d_col_iters, 0, (size_t)c->D * sizeof(int32_t), ctx->stream));
     }
@@ -330,6 +334,8 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             p.n_cap = L.n_cap;
             p.tile_stride = L.tile_stride;
             p.handoff_on = c->compact_ready && compact_handoff_for(ctx, L) > 0 ? 1 : 0;
+            // (a quad class holds one lane shape - its shortest documents at K <= 128 two, of equal capacity)
+            p.handoff_live = p.handoff_on && L.variant == kQuad ? p.handoff_caps[std::min(8, std::max(1, (L.n_cap + kWave - 1) / kWave))] : 0;
             const int class_bracket = open_bracket(slot, ctx->stream);
             if (getenv("PYLDA_DEBUG_SYNC"))
                 fprintf(stderr, "[pylda debug] launching class %d variant %d geometry %d documents %lld n_cap %d handoff %d\n", slot, L.variant, L.rn,
@@ -366,6 +372,7 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         }
         ctx->stream = main_stream;
         p.handoff_on = 0;
+        p.handoff_live = 0;
         if (uber_from >= 0) {
             const Launch& L = c->plan[(size_t)uber_from];
             p.order = c->d_order + L.first;

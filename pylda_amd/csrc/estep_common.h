@@ -42,6 +42,7 @@ struct EstepParams {
     int tile_stride;          // LDS row stride in doubles (odd)
     double* term_scratch;     // nnz scratch doubles, only for documents too long for the LDS (estep_generic.h MODE 2)
     // ---- hand-over to the live-topic kernel (estep_compact.h) ----
+    int handoff_live;         // quad kernel (one lane shape per launch class): its documents leave at this many live topics (0: never)
     int handoff_on;           // 1: a document of N terms leaves the dense kernel once at most handoff_caps[ceil(N / 64)] topics have
     int handoff_caps[9];      //    gamma_k != alpha_k (0: never) - the columns the live-topic kernel's register tile holds at that many
                               //    term slots per lane
@@ -52,7 +53,8 @@ struct EstepParams {
     int live_stats;           // 1: the statistics pass reads the lists (sstats_live.h): the live-topic kernel writes no dense row
     double* live_tile;        // the document's compact tile: value of term n, live topic j at live_tile[tile_ptr[d] + j * N_d + n]
     const int64_t* tile_ptr;  // D offsets into live_tile (doubles)
-    double alpha_max, alpha_min;   // over the K topics (the exactness guard of the live-topic kernel)
+    double alpha_min;         // over the K topics (the exactness guard of the live-topic kernel)
+    const double* alpha_sgn;  // K: alpha with the sign bit set where the topic never counts as dead (kMortalT; alpha_mortality_kernel)
     int32_t* handoff_it;      // D out: inner iterations the dense kernel ran before it handed the document over (else left at -1)
     int32_t* col_iters;       // D out: sum over the live-topic kernel's iterations of the tile columns it ran them on
     double* clock_acc;        // profiling (else NULL): [shader-clock ticks, constant-rate ticks] of sampled kernel spans, accumulated
@@ -65,6 +67,16 @@ __device__ __forceinline__ int handoff_threshold(const EstepParams& p, int N)
     const int cap = p.handoff_on && slots <= 8 ? p.handoff_caps[slots > 0 ? slots : 1] : 0;
     return cap > 0 ? cap : -1;
 }
+
+// A topic may only ever count as DEAD (gamma_k == alpha_k bitwise, dropped from the live-topic kernel's tile) if its
+// t_k = exp(psi(alpha_k) - psi(sum gamma)) is below this: then K t_k is < 2^-60 of any normaliser above 1e-29 and t_k S_k
+// cannot reach half an ulp of alpha_k again whatever the r_n do (guard of estep_compact.h).  A topic with a larger
+// alpha_k - the alpha update of a trained model pushes the used topics' alpha beyond 0.01 - can equal alpha_k bitwise in
+// a document that does not use it (its B are tiny there) while its t_k is only ~1e-20: nothing bounds its share of a
+// normaliser below rounding then.  Such a topic stays a live column for good: the kernels hold its alpha with the sign
+// bit set (EstepParams::alpha_sgn), so that `gamma != alpha` holds for it always (the arithmetic takes |alpha|).  The
+// classification is per topic, once per E-step, for the shortest possible document (psi(sum alpha + 1): the largest t).
+constexpr double kMortalT = 1e-50;
 
 constexpr int kLiveStride = 64;   // entries per document's list: the largest live set the live-topic kernel takes over (two wavefronts x 32 columns)
 // A document's list: [uint16 topic x 64][double t x 64], 640 bytes: a document of <= 16 live topics touches two 128-byte lines

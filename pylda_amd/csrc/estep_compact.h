@@ -24,10 +24,12 @@
 // 2^-40 fixed-point stop sum - a dead topic's |delta gamma| is exactly 0), another summation ORDER inside normalisers and
 // topic sums: results differ from the dense kernel's by rounding (<= a few ulp), from the oracle by the same 1e-13 as
 // before.  What is dropped - the dead topics' B t ~ 1e-114 in the normalisers - is guarded per document from live
-// quantities only: with t_dead = exp(psi(alpha_max) - psi(sum gamma)) >= every dead topic's t,
+// quantities only: with t_dead = exp(psi(max alpha over the dead topics) - psi(sum gamma)) >= every dead topic's t,
 //     K t_dead             <  2^-60 min_n normaliser_n      (a normaliser moves by < 2^-60 relative)
 //     t_dead N max_n r_n   <  2^-54 alpha_min               (fma(t_k, S_k, alpha_k) still rounds to alpha_k: dead stays dead)
-// over ALL iterations run here; a document that fails either is flagged (status 1) and redone by the log-space kernel,
+// over ALL iterations run here (a topic whose t at gamma = alpha is not below kMortalT never counts as dead in the first
+// place - estep_common.h - so the bound holds by a wide margin whenever the normalisers are sane);
+// a document that fails either is flagged (status 1) and redone by the log-space kernel,
 // the reference's own formulation - like a document whose normaliser leaves the fp64 range.
 #pragma once
 #include "estep_common.h"
@@ -127,7 +129,7 @@ struct CompactLds {
     double gam[kLiveStride];        // gamma of the live topics (column order)
     double gprev[kLiveStride];      // ... before the last update
     double tlast[kLiveStride];      // t of the last executed iteration
-    double alf[kLiveStride];        // alpha of the live topics
+    double alf[kLiveStride];        // alpha of the live topics; sign bit: never counts as dead (kMortalT)
     int idx[kLiveStride];           // topic of column j
     int col[kLiveStride];           // its column in the document's tile in memory
     unsigned member[32];            // bit k: topic k is a column (K <= 1024)
@@ -257,7 +259,8 @@ __device__ __forceinline__ int compact_body(const EstepParams& p, int doc, int64
     if (mycol >= L) mycol = -1;
     const bool owns = mycol >= 0, primary = owns && first_replica;
     double gam = owns ? lds.gam[owns ? mycol : 0] : 1.0;
-    const double alpha_k = owns ? lds.alf[owns ? mycol : 0] : 1.0;
+    const double alpha_signed = owns ? lds.alf[owns ? mycol : 0] : 1.0;      // (sign bit: the topic never counts as dead)
+    const double alpha_k = fabs(alpha_signed);
     double t;
     {
         ExpDigammaLevelsA coef_a;
@@ -318,7 +321,7 @@ __device__ __forceinline__ int compact_body(const EstepParams& p, int doc, int64
         --left;
         if (moved <= thresh_f || left <= 0) break;                            // :189, :174
         if (shrink_to > 0) {
-            const int alive = __builtin_popcountll(__ballot(primary && gam != alpha_k));
+            const int alive = __builtin_popcountll(__ballot(primary && gam != alpha_signed));
             if (alive <= shrink_to) {
                 exit_code = kCompactShrink;
                 break;
@@ -384,7 +387,8 @@ __device__ __forceinline__ int compact_pair_body(const EstepParams& p, int doc, 
     if (mycol >= L) mycol = -1;
     const bool owns = mycol >= 0, primary = owns && first_replica;
     double gam = owns ? lds.gam[owns ? mycol : 0] : 1.0;
-    const double alpha_k = owns ? lds.alf[owns ? mycol : 0] : 1.0;
+    const double alpha_signed = owns ? lds.alf[owns ? mycol : 0] : 1.0;      // (sign bit: the topic never counts as dead)
+    const double alpha_k = fabs(alpha_signed);
     double t;
     {
         ExpDigammaLevelsA coef_a;
@@ -462,7 +466,7 @@ __device__ __forceinline__ int compact_pair_body(const EstepParams& p, int doc, 
         t = exp_digamma_minus_levels<true>(gam, psi_total, coef_a, &coef_b);
         if (!owns) t = 0.0;
         moved_mine = wave_sum(moved);
-        alive_mine = __builtin_popcountll(__ballot(primary && gam != alpha_k));
+        alive_mine = __builtin_popcountll(__ballot(primary && gam != alpha_signed));
         ++it;
         --left;
     }
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(TPW > 0 ? 2 * kWave : kWave, 2) void estep_compact_
         lds.idx[lane] = topic;
         lds.col[lane] = lane;
         lds.gam[lane] = p.gamma[(size_t)doc * K + topic];
-        lds.alf[lane] = p.alpha[topic];
+        lds.alf[lane] = p.alpha_sgn[topic];
     }
     // total token count (:162) and psi(sum_k gamma_k), formed as the dense kernels form them (the same bits)
     double local = 0.0;
@@ -594,10 +598,20 @@ __global__ __launch_bounds__(TPW > 0 ? 2 * kWave : kWave, 2) void estep_compact_
     }
     const int L = st.L;
 
-    // ---- the exactness guard (header), from the extremes over every iteration run here ----
+    // ---- the exactness guard (header), from the extremes over every iteration run here.  The dead topics: every topic
+    //      that is not a column now (a column is only ever dropped once its gamma IS alpha_k) - the largest alpha among
+    //      THEM bounds their t (a topic with a large alpha never dies bitwise: it is a column to the end) ----
+    if (lane < 32) lds.member[lane] = 0u;
+    wave_lds_exchange();
+    if (lane < L) atomicOr(&lds.member[lds.idx[lane] >> 5], 1u << (lds.idx[lane] & 31));
+    wave_lds_exchange();
     {
+        double alpha_dead = 0.0;
+        for (int k = lane; k < K; k += kWave)
+            if (!((lds.member[k >> 5] >> (k & 31)) & 1u)) alpha_dead = fmax(alpha_dead, p.alpha[k]);
+        alpha_dead = wave_max(alpha_dead);
         const double nrm_min = wave_min(st.nrm_min), r_max = wave_max(st.r_max);
-        const double t_dead = exp_digamma_minus(p.alpha_max, psi_total);
+        const double t_dead = alpha_dead > 0.0 ? exp_digamma_minus(alpha_dead, psi_total) : 0.0;
         const bool safe = (double)K * t_dead < 8.673617379884035e-19 * nrm_min &&            // 2^-60
                           t_dead * (double)N * r_max < 5.551115123125783e-17 * p.alpha_min;     // 2^-54
         if (!safe) st.bad = 1;
@@ -622,7 +636,7 @@ __global__ __launch_bounds__(TPW > 0 ? 2 * kWave : kWave, 2) void estep_compact_
     const bool mine = lane < L;
     const int at = mine ? lane : 0;
     const int topic = lds.idx[at];
-    const double gam = lds.gam[at], gprev = lds.gprev[at], tlast = lds.tlast[at], alpha_k = lds.alf[at];
+    const double gam = lds.gam[at], gprev = lds.gprev[at], tlast = lds.tlast[at], alpha_k = fabs(lds.alf[at]);
     if (mine) p.gamma[(size_t)doc * K + topic] = gam;
     if (lane == 0) p.col_iters[doc] = st.cols;
     if (!p.heldout) {
@@ -656,11 +670,7 @@ __global__ __launch_bounds__(TPW > 0 ? 2 * kWave : kWave, 2) void estep_compact_
     }
 
     // ---- document terms (:195-204) with the last phi = B t r, as the dense kernels' epilogue (estep_epilogue.h) ----
-    if (lane < 32) lds.member[lane] = 0u;
-    wave_lds_exchange();
-    if (mine) atomicOr(&lds.member[topic >> 5], 1u << (topic & 31));
-    wave_lds_exchange();
-    double term1 = 0.0, term3 = 0.0, shift_term = 0.0;
+    double term1 = 0.0, term3 = 0.0, shift_term = 0.0;      // (lds.member: the columns, from the guard above)
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int n = s * kWave + lane;

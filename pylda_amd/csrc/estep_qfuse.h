@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     asum = wave_sum(asum);
     const bool topic_thread = tid < KT;
     const bool topic_live = tid < K;
-    if (topic_thread) alf[tid] = topic_live ? p.alpha[tid] : 1.0;
+    if (topic_thread) alf[tid] = topic_live ? p.alpha_sgn[tid] : 1.0;      // (alpha; sign bit: the topic never counts as dead, kMortalT)
     if (c == 0) misc[wave] = local;
     // live topics after an iteration (gamma_k != alpha_k bitwise), for the hand-over to the live-topic kernel; and the
     // per-wavefront counts of that exit - both in the idle part of misc
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     const double psi_total = uniform_f64(digamma(asum + total));
     double gam = 1.0;
     if (topic_thread) {
-        gam = topic_live ? alf[tid] + total / K : 1.0;                    // :165 (padding topics never move)
+        gam = topic_live ? fabs(alf[tid]) + total / K : 1.0;              // :165 (padding topics never move)
         tt[tid] = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
     }
     __syncthreads();                                        // t is published; the LDS rows are written (same wavefront reads them)
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
             const double t_mine = tt[buf * KT + tid], alpha_k = alf[tid];
             keep_together(part);
             const double s0 = (part[0] + part[1]) + (part[4] + part[5]), s1 = (part[2] + part[3]) + (part[6] + part[7]);
-            const double gnew = fma(t_mine, s0 + s1, alpha_k);            // :185
+            const double gnew = fma(t_mine, s0 + s1, fabs(alpha_k));      // :185 (the sign bit: a topic that never counts as dead)
             const double diff = topic_live ? fabs(gnew - gam) : 0.0;      // :187
             gpv[tid] = gam;
             gam = gnew;                                                   // :188
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void estep_qfuse_kernel(EstepParams p)
     }
     TopicShare share;
     if (topic_thread)
-        topic_share(p, doc, tid, ldk, topic_live, true, gam, alf[tid], gpv[tid], tt[last * KT + tid], psi_total, share);
+        topic_share(p, doc, tid, ldk, topic_live, true, gam, fabs(alf[tid]), gpv[tid], tt[last * KT + tid], psi_total, share);
     finish_document<W>(p, doc, it, misc, c, wave, tid, term1, term3, shift_term, share);
 }
 

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     for (int n = tid; n < N; n += NT) local += (double)p.term_ct[lo + n];
     double asum = 0.0;
     for (int k = lane; k < K; k += kWave) asum += p.alpha[k];
-    if (tid < KT) alf[tid] = tid < K ? p.alpha[tid] : 1.0;
+    if (tid < KT) alf[tid] = tid < K ? p.alpha_sgn[tid] : 1.0;      // (alpha; sign bit: the topic never counts as dead, kMortalT)
 
     // ---- the tile gather: register slots, then the LDS slots (through registers) ----
     double B[RWL][KRL];
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     // ---- gamma phase state: thread k < KT owns topic k ----
     double gam = 1.0;
     if (topic_thread) {
-        gam = topic_live ? alf[ktid] + total / K : 1.0;                   // :165 (padding topics never move)
+        gam = topic_live ? fabs(alf[ktid]) + total / K : 1.0;             // :165 (padding topics never move)
         tt[ktid] = topic_live ? exp_digamma_minus(gam, psi_total) : 0.0;
     }
     lds_only_barrier();
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     // topics whose gamma differs from alpha (bitwise) after the last update, and the count at which the document
     // leaves this kernel (-1: never)
     int nlive = KT;
-    const int handoff_at = handoff_threshold(p, N);
+    const int handoff_at = p.handoff_live > 0 ? p.handoff_live : -1;      // (one scalar: these kernels have no register to spare for a look-up)
     double tq[KRL];
 #pragma unroll
     for (int jj = 0; jj < KRL / 2; ++jj) {
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
                 s0 += part_sum[4] + part_sum[5];
                 s1 += part_sum[6] + part_sum[7];
             }
-            const double gnew = fma(t_mine, s0 + s1, alpha_k);            // :185
+            const double gnew = fma(t_mine, s0 + s1, fabs(alpha_k));      // :185 (the sign bit: a topic that never counts as dead)
             const double diff = fabs(gnew - gam);                         // :187
             gpv[ktid] = gam;
             gam = gnew;                                                   // :188
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
     }
     TopicShare share;
     if (topic_thread)
-        topic_share(p, doc, ktid, ldk, topic_live, true, gam, alf[ktid], gpv[ktid], tt[last * KT + ktid], psi_total, share);
+        topic_share(p, doc, ktid, ldk, topic_live, true, gam, fabs(alf[ktid]), gpv[ktid], tt[last * KT + ktid], psi_total, share);
     finish_document<W>(p, doc, it, misc, lane, wave, tid, term1, term3, shift_term, share);
 }
 

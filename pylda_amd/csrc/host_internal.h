@@ -66,6 +66,7 @@ struct pylda_ctx {
     double* d_psi_rowsum = nullptr; // K
     double* d_topic_lse = nullptr;  // K
     double* d_alpha = nullptr;      // K
+    double* d_alpha_sgn = nullptr;  // K: alpha, sign bit set where the topic never counts as dead (alpha_mortality_kernel, per E-step)
     double* d_sstats = nullptr;     // V x ldk
     double* d_kv_scratch = nullptr; // K x V (export transposes)
     double* d_beta = nullptr;       // V

@@ -17,16 +17,24 @@ int columns_for(int slots)
     return slots <= 8 ? columns[slots] : 0;
 }
 
+// TPW: columns per wavefront of the two-wavefront first stage, or 0: one wavefront per document from the start
+template <int S, int LTMAX, int TPW>
+int launch_compact_shape(pylda_ctx* ctx, const EstepParams& p, int64_t count)
+{
+    auto kern = estep_compact_kernel<S, LTMAX, TPW>;
+    const size_t lds = compact_lds_bytes(p.ldk, S, TPW);
+    if (lds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(TPW > 0 ? 2 * kWave : kWave), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PYLDA_OK;
+}
+
 template <int S, int LTMAX>
 int launch_compact_as(pylda_ctx* ctx, const EstepParams& p, int64_t count)
 {
-    auto kern = estep_compact_kernel<S, LTMAX, LTMAX>;
-    const size_t lds = compact_lds_bytes(p.ldk, S, LTMAX);
-    if (lds > 64 * 1024)
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(2 * kWave), lds, ctx->stream, p);
-    HIP_TRY(ctx, hipGetLastError());
-    return PYLDA_OK;
+    // (documents are handed over at p.handoff_caps: beyond one wavefront's columns only the pair kernel can take them)
+    return p.handoff_caps[S] > LTMAX ? launch_compact_shape<S, LTMAX, LTMAX>(ctx, p, count) : launch_compact_shape<S, LTMAX, 0>(ctx, p, count);
 }
 
 }  // namespace

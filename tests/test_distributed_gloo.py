@@ -99,15 +99,17 @@ def test_rank_zero_gathers_rows_without_pickling(tmp_path):
                           np.concatenate([np.arange(10, dtype=np.int32), np.arange(6, dtype=np.int32) + 200]))
 
 
-def test_line_ranges_balance_bytes_and_cover():
+def test_line_ranges_balance_tokens_and_cover():
+    """launch_train --gpus N: contiguous line ranges balanced by TOKENS (the proxy for distinct terms known before parsing;
+    ADVICE r5: bytes also weigh long words)."""
     sys.path.insert(0, ROOT)
     from pylda_amd import cli
     rng = np.random.default_rng(0)
-    docs = ["w" * int(n) for n in rng.integers(0, 400, 1000)]
+    docs = [" ".join("w" * int(rng.integers(1, 12)) for _ in range(int(n))) for n in rng.integers(1, 400, 1000)]
     for world in (1, 2, 3, 8):
         b = cli._line_ranges(docs, world)
         assert b[0] == 0 and b[-1] == 1000 and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
-        weights = [sum(len(d) + 1 for d in docs[lo:hi]) for lo, hi in zip(b, b[1:])]
+        weights = [sum(d.count(" ") + 1 for d in docs[lo:hi]) for lo, hi in zip(b, b[1:])]
         assert max(weights) - min(weights) <= 2 * 401                         # within a line or two of each other
     assert cli._line_ranges([], 4) == [0, 0, 0, 0, 0]
     assert cli._line_ranges(["a", "b"], 8)[-1] == 2                           # more ranks than lines: empty shards

@@ -143,6 +143,15 @@ def test_exactness_guard_failure_goes_to_the_log_space_kernel(capi):
     assert np.array_equal(out["iters"], ref["iters"])
     assert rel_err(out["gamma"], ref["gamma"]) < 1e-8 and rel_err(out["doc_ll"], ref["doc_ll"]) < 1e-8
     assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+    # a few topics with a large alpha (the alpha update of a trained model) never die - they stay columns to the end -
+    # and must not trip the guard of the documents around them: the bound is over the DEAD topics' alpha
+    alpha = np.full(K, 1.0 / K)
+    alpha[rng.permutation(K)[:6]] = [0.08, 0.2, 0.05, 0.5, 0.03, 0.1]
+    ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
+    out = run(capi, K, V, ptr, ids, cts, alpha, eta)
+    assert out["handed_over"] > 0 and out["flagged"] == 0
+    assert np.array_equal(out["iters"], ref["iters"]) and rel_err(out["doc_ll"], ref["doc_ll"]) < LL_RTOL
+    assert rel_err(out["gamma"], ref["gamma"]) < GAMMA_RTOL_ORACLE and np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
     # ... and alpha too large for any topic to die bitwise: nothing is handed over, nothing flagged
     alpha = np.full(K, 0.3)
     ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)

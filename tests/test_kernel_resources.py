@@ -41,7 +41,7 @@ def test_quad_kernels_keep_their_tile_in_registers():
 
 def test_live_topic_kernels_have_no_scratch_in_their_loops():
     res, hot = _analyse("launch_compact.hip")
-    assert len(res) == 8, sorted(res)                    # one per lane shape: 1 .. 8 term slots per lane
+    assert len(res) == 16, sorted(res)                   # lane shapes 1 .. 8 term slots per lane, one or two wavefronts per document
     for name, info in res.items():
         assert info["NumVgprs"] <= 256 and info["Occupancy"] >= 2, (name, info)      # two wavefronts per SIMD
         assert info["ScratchSize"] <= 96, (name, info)                                 # (prologue / epilogue only)
