@@ -34,18 +34,27 @@ __global__ __launch_bounds__(256) void doc_terms_kernel(EstepParams p, int64_t c
     const double* gamma = p.gamma + (size_t)doc * K;
     const double* t = p.tfinal + (size_t)doc * p.ldk;
     double lgam = 0.0, gsum = 0.0, term2 = 0.0, term3 = 0.0;
-    // a document the live-topic kernel finished keeps t as a list of its live topics (a dead topic has mass 0: no term)
+    // a document the live-topic kernel finished keeps t as a list of its live topics; every other topic sits at alpha_k
+    // EXACTLY (mass 0: no term), so the two sums over the K topics are the corpus constants plus the live topics' shares:
+    //   sum_k lnG(gamma_k) = sum_k lnG(alpha_k) + sum_live (lnG(gamma_j) - lnG(alpha_j)),  sum_k gamma_k likewise
+    // - a dozen lnG evaluations per document instead of K, and the 2-KiB gamma row is not read
     const int listed = p.live_stats ? p.live_n[doc] : -1;
-    for (int k = lane; k < K; k += kWave) {
-        const double g = gamma[k], mass = g - p.alpha[k];                 // = t_k * sum_n r_n B[w_n][k]
-        lgam += lgamma_pos(g);
-        gsum += g;
-        if (listed < 0 && mass != 0.0) term2 = fma(log(t[k]), mass, term2);   // (t_k may have underflowed where the mass did)
-    }
-    if (lane < listed) {
-        const int k = live_idx_of(p.live_list, doc)[lane];
-        const double mass = gamma[k] - p.alpha[k];
-        if (mass != 0.0) term2 = fma(log(live_t_of(p.live_list, doc)[lane]), mass, term2);
+    if (listed >= 0) {
+        if (lane < listed) {
+            char* list = live_list_of(p.live_list, doc);
+            const int k = *live_idx_at(list, lane);
+            const double g = gamma[k], a = p.alpha[k], mass = g - a;      // mass = t_k * sum_n r_n B[w_n][k]
+            lgam = lgamma_pos(g) - lgamma_pos(a);
+            gsum = mass;
+            if (mass != 0.0) term2 = log(*live_t_at(list, lane)) * mass;  // (t_k may have underflowed where the mass did)
+        }
+    } else {
+        for (int k = lane; k < K; k += kWave) {
+            const double g = gamma[k], mass = g - p.alpha[k];
+            lgam += lgamma_pos(g);
+            gsum += g;
+            if (mass != 0.0) term2 = fma(log(t[k]), mass, term2);
+        }
     }
     const int64_t lo = p.doc_ptr[doc], hi = p.doc_ptr[doc + 1];
     for (int64_t n = lo + lane; n < hi; n += kWave) {
@@ -54,6 +63,10 @@ __global__ __launch_bounds__(256) void doc_terms_kernel(EstepParams p, int64_t c
     }
     lgam = wave_sum(lgam);
     gsum = wave_sum(gsum);
+    if (listed >= 0) {
+        lgam += p.alpha_lgamma_sum;
+        gsum += p.alpha_sum;
+    }
     term2 = wave_sum(term2);
     term3 = wave_sum(term3);
     if (lane == 0) {

@@ -237,6 +237,8 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         alg += std::lgamma(a);
     }
     p.alpha_term = std::lgamma(asum) - alg;                           // :195
+    p.alpha_sum = asum;
+    p.alpha_lgamma_sum = alg;
     p.doc_ptr = c->d_doc_ptr;
     p.term_id = c->d_term_id;
     p.term_ct = c->d_term_ct;

@@ -21,6 +21,7 @@ struct EstepParams {
     const double* topic_lse;  // K     : logsumexp_v E_log_eta[k][:]  (held-out only, :155)
     const double* alpha;      // K
     double alpha_term;        // lnG(sum alpha) - sum lnG(alpha)      (:195)
+    double alpha_sum, alpha_lgamma_sum;   // sum_k alpha_k, sum_k lnG(alpha_k)
     const int64_t* doc_ptr;   // D+1
     const int32_t* term_id;   // nnz
     const int32_t* term_ct;   // nnz
@@ -69,23 +70,37 @@ __device__ __forceinline__ int handoff_threshold(const EstepParams& p, int N)
 }
 
 // A topic may only ever count as DEAD (gamma_k == alpha_k bitwise, dropped from the live-topic kernel's tile) if its
-// t_k = exp(psi(alpha_k) - psi(sum gamma)) is below this: then K t_k is < 2^-60 of any normaliser above 1e-29 and t_k S_k
-// cannot reach half an ulp of alpha_k again whatever the r_n do (guard of estep_compact.h).  A topic with a larger
-// alpha_k - the alpha update of a trained model pushes the used topics' alpha beyond 0.01 - can equal alpha_k bitwise in
-// a document that does not use it (its B are tiny there) while its t_k is only ~1e-20: nothing bounds its share of a
-// normaliser below rounding then.  Such a topic stays a live column for good: the kernels hold its alpha with the sign
-// bit set (EstepParams::alpha_sgn), so that `gamma != alpha` holds for it always (the arithmetic takes |alpha|).  The
-// classification is per topic, once per E-step, for the shortest possible document (psi(sum alpha + 1): the largest t).
-constexpr double kMortalT = 1e-50;
+// t_k = exp(psi(alpha_k) - psi(sum gamma)) is below this for a document of kMortalTokens tokens.  For a topic with a
+// larger alpha_k - the alpha update of a trained model pushes the used topics' alpha beyond 0.01 - gamma_k can equal
+// alpha_k bitwise in a document that does not use it (its B are tiny there) while t_k is only ~1e-20: nothing bounds
+// its share of a normaliser below rounding then, and the guard of estep_compact.h (K t_dead < 2^-60 of the smallest
+// normaliser, t_dead N r_max < 2^-54 alpha_min - evaluated per document, with the document's own psi(sum gamma)) would
+// send every such document to the log-space kernel.  Such a topic stays a live column for good instead: the kernels
+// hold its alpha with the sign bit set (EstepParams::alpha_sgn), so that `gamma != alpha` holds for it always (the
+// arithmetic takes |alpha|).  With 1e-33 the guard passes for normalisers above ~1e-14 and r_n below ~1e12 - a document
+// outside that (or much shorter than kMortalTokens) is what the guard and the log-space kernel are for.
+constexpr double kMortalT = 1e-33;
+constexpr double kMortalTokens = 8.0;
 
-constexpr int kLiveStride = 64;   // entries per document's list: the largest live set the live-topic kernel takes over (two wavefronts x 32 columns)
-// A document's list: [uint16 topic x 64][double t x 64], 640 bytes: a document of <= 16 live topics touches two 128-byte lines
-constexpr int kLiveListBytes = kLiveStride * 2 + kLiveStride * 8;
-__device__ __forceinline__ uint16_t* live_idx_of(char* live_list, int64_t doc) { return reinterpret_cast<uint16_t*>(live_list + doc * kLiveListBytes); }
-__device__ __forceinline__ double* live_t_of(char* live_list, int64_t doc)
+constexpr int kLiveStride = 60;   // entries per document's list: the largest live set the live-topic kernel takes over
+// A document's list of live topics (EstepParams::live_list), 640 bytes = five 128-byte lines:
+//     line 0        t[0 .. 12) (96 bytes), then topic[0 .. 12) as uint16 (24 bytes)
+//     lines 1-3     t[12 .. 60)
+//     line 4        topic[12 .. 60)
+// The statistics pass reads a document's list once per posting, at random over the corpus: nineteen in twenty documents
+// finish with at most twelve live topics (cfg 4: seven on average) and cost it ONE line.
+constexpr int kLiveHead = 12;
+constexpr int kLiveListBytes = 640;
+__device__ __forceinline__ double* live_t_at(char* list, int j)
 {
-    return reinterpret_cast<double*>(live_list + doc * kLiveListBytes + kLiveStride * 2);
+    return reinterpret_cast<double*>(list + (j < kLiveHead ? 8 * j : 128 + 8 * (j - kLiveHead)));
 }
+__device__ __forceinline__ uint16_t* live_idx_at(char* list, int j)
+{
+    return reinterpret_cast<uint16_t*>(list + (j < kLiveHead ? 96 + 2 * j : 512 + 2 * (j - kLiveHead)));
+}
+__device__ __forceinline__ char* live_list_of(char* live_list, int64_t doc) { return live_list + doc * kLiveListBytes; }
+static_assert(128 + 8 * (kLiveStride - kLiveHead) == 512 && 512 + 2 * (kLiveStride - kLiveHead) <= kLiveListBytes, "list layout");
 
 // Sum over the 64 lanes, result in every lane, without the LDS crossbar (ds_bpermute costs an LDS
 // round trip per level): four DPP levels inside each 16-lane row, then one permlane16 and one

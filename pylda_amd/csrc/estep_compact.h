@@ -523,7 +523,7 @@ __global__ __launch_bounds__(TPW > 0 ? 2 * kWave : kWave, 2) void estep_compact_
     const int L0 = p.live_n[doc];
 
     if (wave == 0 && lane < L0) {
-        const int topic = live_idx_of(p.live_list, doc)[lane];
+        const int topic = *live_idx_at(live_list_of(p.live_list, doc), lane);
         lds.idx[lane] = topic;
         lds.col[lane] = lane;
         lds.gam[lane] = p.gamma[(size_t)doc * K + topic];
@@ -642,8 +642,8 @@ __global__ __launch_bounds__(TPW > 0 ? 2 * kWave : kWave, 2) void estep_compact_
     if (!p.heldout) {
         if (p.live_stats) {
             if (mine) {
-                live_idx_of(p.live_list, doc)[lane] = (uint16_t)topic;
-                live_t_of(p.live_list, doc)[lane] = tlast;
+                *live_idx_at(live_list_of(p.live_list, doc), lane) = (uint16_t)topic;
+                *live_t_at(live_list_of(p.live_list, doc), lane) = tlast;
             }
             if (lane == 0) p.live_n[doc] = L;
         } else {

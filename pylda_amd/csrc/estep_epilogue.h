@@ -93,7 +93,7 @@ __device__ __forceinline__ void stream_hand_over(const EstepParams& p, int doc, 
     __syncthreads();
     int at = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
     for (int w = 0; w < wave; ++w) at += (int)counts[w];
-    if (alive) live_idx_of(p.live_list, doc)[at] = (uint16_t)tid;
+    if (alive) *live_idx_at(live_list_of(p.live_list, doc), at) = (uint16_t)tid;
     if (topic_live) p.gamma[(size_t)doc * p.K + tid] = gam;
     if (tid == 0) {
         unsigned total = 0;

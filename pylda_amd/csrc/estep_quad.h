@@ -106,7 +106,7 @@ __device__ __forceinline__ void quad_hand_over(const EstepParams& p, char* smem,
         int at = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
         for (int w = 0; w < trank; ++w) at += (int)wcount[w];
         pos[ktid] = alive ? at : -1;
-        if (alive) live_idx_of(p.live_list, doc)[at] = (uint16_t)ktid;
+        if (alive) *live_idx_at(live_list_of(p.live_list, doc), at) = (uint16_t)ktid;
         if (ktid < K) p.gamma[(size_t)doc * K + ktid] = gam;
     }
     __syncthreads();

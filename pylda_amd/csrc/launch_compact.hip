@@ -13,7 +13,7 @@ namespace {
 int slots_for(int n) { return std::max(1, (n + kWave - 1) / kWave); }
 int columns_for(int slots)
 {
-    static const int columns[9] = {0, 32, 32, 28, 20, 16, 12, 8, 8};
+    static const int columns[9] = {0, 28, 28, 28, 20, 16, 12, 8, 8};      // (two wavefronts of 28: 56 of the list's 60 entries)
     return slots <= 8 ? columns[slots] : 0;
 }
 
@@ -134,8 +134,8 @@ int launch_compact(pylda_ctx* ctx, const pylda_corpus* c, EstepParams p, int slo
     p.order = c->d_order + first;
     p.tile_from_table = from_table ? 1 : 0;
     switch (slots) {
-    case 1: return launch_compact_as<1, 32>(ctx, p, count);
-    case 2: return launch_compact_as<2, 32>(ctx, p, count);
+    case 1: return launch_compact_as<1, 28>(ctx, p, count);
+    case 2: return launch_compact_as<2, 28>(ctx, p, count);
     case 3: return launch_compact_as<3, 28>(ctx, p, count);
     case 4: return launch_compact_as<4, 20>(ctx, p, count);
     case 5: return launch_compact_as<5, 16>(ctx, p, count);

@@ -160,14 +160,14 @@ __global__ __launch_bounds__(1024) void vector_sum3_kernel(SumJob a, SumJob b, S
 }
 
 // alpha with the sign bit set where the topic may never count as dead (estep_common.h kMortalT): its t at gamma = alpha,
-// exp(psi(alpha_k) - psi(sum gamma)), is not negligible even for the shortest document (sum gamma = sum alpha + 1 token:
-// the smallest psi(sum gamma), the largest t).  One workgroup, once per E-step.
+// exp(psi(alpha_k) - psi(sum gamma)), is not negligible in a short document (sum gamma = sum alpha + kMortalTokens).
+// One workgroup, once per E-step.
 __global__ __launch_bounds__(256) void alpha_mortality_kernel(const double* __restrict__ alpha, int K, double* __restrict__ alpha_sgn)
 {
     __shared__ double scratch[4];
     double a = 0.0;
     for (int k = threadIdx.x; k < K; k += 256) a += alpha[k];
-    const double psi_shortest = digamma(block_sum<256>(a, scratch) + 1.0);
+    const double psi_shortest = digamma(block_sum<256>(a, scratch) + kMortalTokens);
     for (int k = threadIdx.x; k < K; k += 256) {
         const double ak = alpha[k];
         alpha_sgn[k] = exp_digamma_minus(ak, psi_shortest) < kMortalT ? ak : -ak;

@@ -222,6 +222,9 @@ int build_postings(pylda_corpus* c)
     return PYLDA_OK;
 }
 
+#ifndef PYLDA_LIVE_U
+#define PYLDA_LIVE_U 4         // postings whose lists are in flight together in the live-list pass (sstats_live.h)
+#endif
 #ifndef PYLDA_GATHER_U
 #define PYLDA_GATHER_U 4        // rows in flight per wavefront (cfg 3, 24 blocks: 4 -> 1.62 ms, 8 -> 1.71, 16 -> 2.3: occupancy)
 #endif
@@ -290,10 +293,10 @@ int enqueue_sstats_gather(pylda_ctx* ctx, pylda_corpus* c)
 #define LIVE_ARGS c->d_seg_begin, c->d_seg_end, c->nseg, c->d_post_doc
 #define LIVE_TAIL c->d_tfinal, c->d_rfinal, c->d_live_n, c->d_live_list, ldk, c->d_partial
             if (c->wide_pos)
-                hipLaunchKernelGGL((sstats_gather_live_kernel<4, int64_t>), grid, dim3(256), lds, ctx->stream, LIVE_ARGS,
+                hipLaunchKernelGGL((sstats_gather_live_kernel<PYLDA_LIVE_U, int64_t>), grid, dim3(256), lds, ctx->stream, LIVE_ARGS,
                                    static_cast<const int64_t*>(c->d_post_pos), LIVE_TAIL);
             else
-                hipLaunchKernelGGL((sstats_gather_live_kernel<4, int32_t>), grid, dim3(256), lds, ctx->stream, LIVE_ARGS,
+                hipLaunchKernelGGL((sstats_gather_live_kernel<PYLDA_LIVE_U, int32_t>), grid, dim3(256), lds, ctx->stream, LIVE_ARGS,
                                    static_cast<const int32_t*>(c->d_post_pos), LIVE_TAIL);
 #undef LIVE_ARGS
 #undef LIVE_TAIL

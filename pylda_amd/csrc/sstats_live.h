@@ -3,7 +3,7 @@
 // sstats_kernels.h / sstats_sweep.h gather, per posting (term w, document d), the document's whole row t_d[0 .. ldk):
 // 2 KiB at K = 256 of which - once the live-topic kernel (estep_compact.h) has finished the document - all but a
 // dozen entries are exactly the dead topics' 1e-114, i.e. nothing a statistic can see (eta = statistics + beta).  Those
-// documents now leave a list: up to 32 (topic, t) pairs in 320 bytes (EstepParams::live_list), and this pass adds
+// documents now leave a list: up to 60 (topic, t) pairs, the first twelve in ONE 128-byte line (estep_common.h), and this pass adds
 //
 //     acc[w][k_j] += r_dw t_dj        for the entries j of the list of d
 //
@@ -14,8 +14,8 @@
 // short prefix, another kernel family, the safety net) adds its row tfinal[d] instead.  The finalize pass
 // (sstats_kernels.h) sums a term's segment rows in order and applies B[w][k], as for the dispatch-paced gather.
 //
-// Per posting the pass moves ~200 bytes (the list; r_dw; 12 bytes of posting) instead of 2 KiB, and the lists of the whole
-// corpus (cfg 4: 1M x 320 B) fit the Infinity Cache: no document blocking, no rendezvous, no sweep.
+// Per posting the pass moves ~200 bytes (a line of the list; r_dw; 12 bytes of posting) instead of 2 KiB, and the lists' first
+// lines of the whole corpus (cfg 4: 1M x 128 B) fit the Infinity Cache: no document blocking, no rendezvous, no sweep.
 #pragma once
 #include "estep_common.h"
 
@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256) void sstats_gather_live_kernel(
                     const int entries = p + u < n ? __builtin_amdgcn_readlane(listed, at) : 0;
                     rr[u] = readlane_f64(r, at);
                     on[u] = lane < entries;
-                    const char* list = live_list + (size_t)doc * kLiveListBytes;
-                    k[u] = on[u] ? reinterpret_cast<const uint16_t*>(list)[lane] : 0;
-                    t[u] = on[u] ? reinterpret_cast<const double*>(list + kLiveStride * 2)[lane] : 0.0;
+                    char* list = live_list_of(const_cast<char*>(live_list), doc);
+                    k[u] = on[u] ? *live_idx_at(list, lane) : 0;
+                    t[u] = on[u] ? *live_t_at(list, lane) : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)                     // posting order: the LDS keeps a wavefront's instructions in order
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void sstats_gather_live_kernel(
                 const double rr = readlane_f64(r, p);
                 if (entries >= 0) {
                     if (lane < entries) {
-                        const char* list = live_list + (size_t)doc * kLiveListBytes;
-                        const int k = reinterpret_cast<const uint16_t*>(list)[lane];
-                        const double t = reinterpret_cast<const double*>(list + kLiveStride * 2)[lane];
+                        char* list = live_list_of(const_cast<char*>(live_list), doc);
+                        const int k = *live_idx_at(list, lane);
+                        const double t = *live_t_at(list, lane);
                         __hip_atomic_fetch_add(acc + k, rr * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 } else {
