@@ -339,7 +339,9 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             // (a quad class holds one lane shape - its shortest documents at K <= 128 two, of equal capacity)
             p.handoff_live = p.handoff_on && L.variant == kQuad ? p.handoff_caps[std::min(8, std::max(1, (L.n_cap + kWave - 1) / kWave))] : 0;
             const int class_bracket = open_bracket(slot, ctx->stream);
-            if (getenv("PYLDA_DEBUG_SYNC"))
+            // PYLDA_DEBUG_SYNC=1: fault localisation - a line before every launch, a wait and the stream's status behind it
+            static const bool debug_sync = getenv("PYLDA_DEBUG_SYNC") != nullptr;
+            if (debug_sync)
                 fprintf(stderr, "[pylda debug] launching class %d variant %d geometry %d documents %lld n_cap %d handoff %d\n", slot, L.variant, L.rn,
                         (long long)L.count, L.n_cap, p.handoff_on);
             switch (L.variant) {
@@ -351,7 +353,6 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
             case kQfusek: rc = launch_qfusek(ctx, p, L); break;
             default: rc = launch_generic_any(ctx, p, L); break;      // the generic family (tile in LDS / re-read from the table)
             }
-            static const bool debug_sync = getenv("PYLDA_DEBUG_SYNC") != nullptr;      // (fault localisation: wait after every launch)
             if (debug_sync) {
                 const hipError_t e = hipStreamSynchronize(ctx->stream);
                 fprintf(stderr, "[pylda debug] class %d variant %d geometry %d documents %lld handoff %d: %s\n", slot, L.variant, L.rn,
