@@ -147,19 +147,47 @@ enum CompactExit { kCompactDone = 0, kCompactShrink = 1 };
 
 // Where a lane's tile values come from: the columns the dense quad kernel wrote (live_tile, term-minor), or - documents of
 // the streaming kernels, which keep no tile on chip to write - the table itself (N x L scattered reads, once per body).
+// A slot beyond the document repeats the document's LAST term: its count is 0, so r = 0 there, and the extremes the
+// exactness guard takes over the normalisers see nothing new.
 template <int S>
 struct CompactSource {
-    const double* tile;     // the document's columns, or nullptr
+    const double* tile;     // the document's columns (uniform), or nullptr
     const double* table;    // expElog
     int ldk, N;
-    int wid[S];             // table mode: term ids of this lane's slots (-1 beyond the document)
-    __device__ __forceinline__ double value(int s, int lane, int column, int topic) const
-    {
-        const int n = s * kWave + lane;
-        if (n >= N) return 1.0;                                           // a slot beyond the document: ones, count 0
-        return tile ? tile[(size_t)column * N + n] : table[(size_t)wid[s] * ldk + topic];
-    }
+    int wid[S];             // table mode: term ids of this lane's slots
+    unsigned at[S];         // tile mode: byte offset of this lane's slots within a column
 };
+
+// The register tile of a body: C[s][m] = value of term lane + 64 s in column STRIDE m + first.  Addresses are a scalar
+// column base plus a 32-bit lane offset (tile mode) or a lane's row pointer plus a scalar topic (table mode): two or three
+// instructions per element, every load in flight at once.  A column beyond L repeats column 0 - nobody owns it, its
+// t_j is 0 (finite values are all that is asked of it).
+template <int S, int LT, int STRIDE>
+__device__ __forceinline__ void compact_load_tile(double (&C)[S][LT], const CompactSource<S>& src, const CompactLds& lds, int L, int first)
+{
+    if (src.tile != nullptr) {
+        const char* base = reinterpret_cast<const char*>(src.tile);
+        const size_t pitch = (size_t)src.N * sizeof(double);
+#pragma unroll
+        for (int m = 0; m < LT; ++m) {
+            const int j = STRIDE * m + first, from = j < L ? j : 0;
+            const char* column = base + (size_t)__builtin_amdgcn_readfirstlane(lds.col[from]) * pitch;
+#pragma unroll
+            for (int s = 0; s < S; ++s) C[s][m] = *reinterpret_cast<const double*>(column + src.at[s]);
+        }
+    } else {
+        const double* row[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) row[s] = src.table + (size_t)src.wid[s] * src.ldk;
+#pragma unroll
+        for (int m = 0; m < LT; ++m) {
+            const int j = STRIDE * m + first, from = j < L ? j : 0;
+            const int topic = __builtin_amdgcn_readfirstlane(lds.idx[from]);
+#pragma unroll
+            for (int s = 0; s < S; ++s) C[s][m] = row[s][topic];
+        }
+    }
+}
 
 // this lane's column after the reduce-scatter of LT values (the recursion of compact_column_of on the lane's bits, shape
 // constants folded), or -1; `first`: the replica with the lowest lane number
@@ -238,7 +266,7 @@ __device__ __forceinline__ int compact_body(const EstepParams& p, int doc, int64
     const int lane = threadIdx.x & (kWave - 1);
     const int L = st.L;
 
-    // the tile: C[s][j] = value of term lane + 64 s, column j; a column beyond L: zeros (t_j = 0 as well)
+    // the tile: C[s][j] = value of term lane + 64 s, column j
     double C[S][LT];
     double cnt[S];
 #pragma unroll
@@ -246,13 +274,7 @@ __device__ __forceinline__ int compact_body(const EstepParams& p, int doc, int64
         const int n = s * kWave + lane;
         cnt[s] = n < N ? (double)p.term_ct[lo + n] : 0.0;
     }
-#pragma unroll
-    for (int j = 0; j < LT; ++j) {
-        const int at = j < L ? j : 0;
-        const int cj = __builtin_amdgcn_readfirstlane(lds.col[at]), topic = __builtin_amdgcn_readfirstlane(lds.idx[at]);
-#pragma unroll
-        for (int s = 0; s < S; ++s) C[s][j] = j < L ? src.value(s, lane, cj, topic) : 0.0;
-    }
+    compact_load_tile<S, LT, 1>(C, src, lds, L, 0);
 
     bool first_replica = false;
     int mycol = compact_my_column<LT>(lane, &first_replica);
@@ -374,13 +396,7 @@ __device__ __forceinline__ int compact_pair_body(const EstepParams& p, int doc, 
         const int n = s * kWave + lane;
         cnt[s] = n < N ? (double)p.term_ct[lo + n] : 0.0;
     }
-#pragma unroll
-    for (int m = 0; m < TPW; ++m) {
-        const int j = 2 * m + wave, at = j < L ? j : 0;
-        const int cj = __builtin_amdgcn_readfirstlane(lds.col[at]), topic = __builtin_amdgcn_readfirstlane(lds.idx[at]);
-#pragma unroll
-        for (int s = 0; s < S; ++s) C[s][m] = j < L ? src.value(s, lane, cj, topic) : 0.0;
-    }
+    compact_load_tile<S, TPW, 2>(C, src, lds, L, wave);
     bool first_replica = false;
     const int mine_local = compact_my_column<TPW>(lane, &first_replica);
     int mycol = mine_local >= 0 ? 2 * mine_local + wave : -1;
@@ -544,7 +560,11 @@ __global__ __launch_bounds__(TPW > 0 ? 2 * kWave : kWave, 2) void estep_compact_
     src.ldk = ldk;
     src.N = N;
 #pragma unroll
-    for (int s = 0; s < S; ++s) src.wid[s] = p.tile_from_table && s * kWave + lane < N ? p.term_id[lo + s * kWave + lane] : 0;
+    for (int s = 0; s < S; ++s) {
+        const int n = s * kWave + lane < N ? s * kWave + lane : N - 1;
+        src.at[s] = (unsigned)n * (unsigned)sizeof(double);
+        src.wid[s] = p.tile_from_table ? p.term_id[lo + n] : 0;
+    }
     if constexpr (TPW > 0) lds_only_barrier();
     else wave_lds_exchange();
 

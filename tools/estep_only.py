@@ -1,4 +1,4 @@
-"""E-steps of the bench's timed window alone, for a profiler: python tools/estep_only.py cfg3|cfg4 [docs] [esteps] [name=value ...]
+"""E-steps of the bench's timed window alone, for a profiler: python tools/estep_only.py cfg3|cfg4 [docs] [esteps] [name=value ...] [max_iter=N]
 (3 learning() iterations from the seeded start, then `esteps` training E-steps of the next outer iteration, fast path)."""
 import os
 import sys
@@ -24,9 +24,13 @@ vb = VariationalBayes(hyper_parameter_optimize_interval=1, device=0)
 vb._verbose = False
 vb._initialize_parsed(ptr, ids, cts, V, K, 1.0 / K, 1.0 / V, eta=eta0)
 ctx = vb._context()
+max_iter = 50
 for opt in sys.argv[4:]:
     k, v = opt.split("=")
-    ctx.set_option(k, int(v))
+    if k == "max_iter":         # (the timed E-steps only: the model is the one three full learning() iterations leave)
+        max_iter = int(v)
+    else:
+        ctx.set_option(k, int(v))
 for _ in range(3):
     vb.learning()
 vb._push_model()
@@ -34,7 +38,7 @@ corpus = vb._train_corpus
 ctx.set_profiling(True)
 ctx.kernel_time()
 for _ in range(esteps):
-    ctx.estep(corpus, 50, 1e-6, False)
+    ctx.estep(corpus, max_iter, 1e-6, False)
 ctx.synchronize()
 doc_ms, ss_ms, calls = ctx.kernel_time()
-print("doc kernels %.3f ms, statistics %.3f ms per E-step (%d E-steps)" % (doc_ms / calls, ss_ms / calls, calls))
+print("doc kernels %.3f ms, statistics %.3f ms per E-step (%d E-steps, inner iteration cap %d)" % (doc_ms / calls, ss_ms / calls, calls, max_iter))
