@@ -12,7 +12,7 @@ def sweep(budget=60.0, seed=0, verbose=True):
     rng = np.random.default_rng(seed)
     t0 = time.time()
     cases = worst_ll = worst_g = worst_fast = worst_ss = 0
-    flips = docs = 0
+    flips = docs = handed = 0
     while time.time() - t0 < budget:
         K = int(rng.choice([1, 2, 7, 10, 16, 31, 33, 64, 65, 100, 127, 128, 129, 160, 192, 200, 255, 256, 257, 300, 384, 400, 500, 512,
                             513, 640, 700, 768, 800, 1000, 1024, 1100]))
@@ -28,6 +28,20 @@ def sweep(budget=60.0, seed=0, verbose=True):
         eta = rng.gamma(100.0, 0.01, (K, V))
         if rng.random() < 0.5:
             eta[:, rng.choice(V, V // 3, replace=False)] = 1.0 / V
+        topical = rng.random() < 0.4
+        if topical:             # a model that knows topics with vocabularies of their own: most topics of a document die, documents are handed over
+            true_topics = int(rng.choice([4, 12, 24, 40]))
+            beta = rng.dirichlet(np.full(V, 0.02), size=true_topics)
+            for k in range(K):
+                eta[k] += 40.0 * V * beta[k % true_topics] * rng.uniform(0.2, 1.0)
+            if rng.random() < 0.7:      # ... and documents drawn from it
+                ptr, ids, cts = [0], [], []
+                for _ in range(D):
+                    theta = rng.dirichlet(np.full(true_topics, float(rng.choice([0.02, 0.1, 0.4]))))
+                    words = rng.choice(V, size=max(1, int(rng.poisson(mean_len))), p=theta @ beta)
+                    u, c = np.unique(words, return_counts=True)
+                    ids.append(u.astype(np.int32)); cts.append(c.astype(np.int32)); ptr.append(ptr[-1] + len(u))
+                ptr = np.array(ptr, np.int64); ids = np.concatenate(ids); cts = np.concatenate(cts)
         # (small alpha: topics die - gamma_k == alpha_k bitwise - and documents go to the live-topic kernel)
         alpha = rng.uniform(0.02, 1.5, K) if rng.random() < 0.5 else np.full(K, float(rng.choice([0.005, 0.05, 1.0 / K, 1.0 / K, 0.5 / K])))
         tol = float(rng.choice([1e-6, 1e-6, 1e-4, 1e-8]))
@@ -41,13 +55,19 @@ def sweep(budget=60.0, seed=0, verbose=True):
         ctx.set_option("compact", int(rng.choice([0, 1, 1, 1])))                    # hand-over to the live-topic kernel (64 < K <= 256) ...
         ctx.set_option("compact_cap", int(rng.choice([0, 0, 8, 12, 17])))           # ... at its capacity, or earlier shapes of it
         ctx.set_option("compact_phase", int(rng.choice([0, 1])))
+        ctx.set_option("compact_pair", int(rng.choice([-1, -1, 0, 1])))             # ... the two-wavefront stage in front of it
+        ctx.set_option("compact_stream", int(rng.choice([0, 1, 1])))                # ... behind the fused streaming kernel (256 < K <= 512)
         ctx.set_option("gather_live", int(rng.choice([0, 1, 1])))                   # statistics from the lists of live topics
         ctx.set_option("wide_postings", int(rng.choice([0, 0, 1])))
         corpus = ctx.corpus(ptr, ids, cts)
         out = ctx.estep_host(corpus, alpha, eta, 50, tol, False)
         ctx.set_option("doc_values", 0)
+        ctx.set_profiling(True)
+        ctx.work_counters()
         ctx.estep(corpus, 50, tol, False)
         fast = ctx.estep_results(corpus)[0]
+        ctx.work_counters()
+        handed += int(ctx.executed_work()[1])
         same = out["iters"] == ref["iters"]
         flips += int((~same).sum()); docs += D
         if same.any():
@@ -70,10 +90,10 @@ def sweep(budget=60.0, seed=0, verbose=True):
                          out["gamma"][d, k], ref["gamma"][d, k], alpha[k]))
         corpus.close(); ctx.close()
         cases += 1
-    summary = {"cases": cases, "documents": docs, "flips": flips, "worst_rel_doc_ll": worst_ll, "worst_rel_gamma": worst_g,
+    summary = {"cases": cases, "documents": docs, "handed_to_live_topic_kernel": handed, "flips": flips, "worst_rel_doc_ll": worst_ll, "worst_rel_gamma": worst_g,
                "worst_fast_path_corpus_ll": worst_fast, "worst_abs_statistics": worst_ss}
-    print("fuzz: %d cases, %d documents, %d iteration-count flips; worst rel doc-LL %.2e, gamma %.2e, fast-path corpus LL %.2e, statistics abs %.2e"
-          % (cases, docs, flips, worst_ll, worst_g, worst_fast, worst_ss))
+    print("fuzz: %d cases, %d documents (%d through the live-topic kernel), %d iteration-count flips; worst rel doc-LL %.2e, gamma %.2e, fast-path corpus LL %.2e, statistics abs %.2e"
+          % (cases, docs, handed, flips, worst_ll, worst_g, worst_fast, worst_ss))
     return summary
 
 
