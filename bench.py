@@ -378,7 +378,11 @@ def measure(job, args, name, steps, warmup, docs=None):
     B = algorithmic_bytes(nnz_local, D_local, K)
     kernel_ms = doc_ms + ss_ms
     achieved = B / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic, traffic_source = traffic_record(name if docs is None else None)
+    # (the committed passes profiled the whole corpus on ONE GPU: they describe this rank's launch only if it holds all of it)
+    whole = docs is None and (job.world == 1 or wl["scaling"] == "weak")
+    traffic, traffic_source = traffic_record(name if whole else None)
+    if not whole and docs is None:
+        traffic_source = "profiles/traffic_%s.json describes the whole corpus on one GPU; rank 0 holds 1 / %d of it here" % (name, job.world)
     flops = 4.0 * K * sum_iter_terms / calls          # two mat-vecs per inner iteration actually executed, rank 0
     tflops = flops / (doc_ms * 1e-3) / 1e12 if doc_ms > 0 else 0.0
     # ... of which the kernels ran only the live part through the FMA pipes: the dense kernels K columns per term and
