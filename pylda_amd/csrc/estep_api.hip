@@ -218,6 +218,15 @@ int pylda_estep(pylda_ctx* ctx, pylda_corpus* c, int max_iter, double tol, int h
         ctx->exact_stop = !(span >= 3.725290298461914e-09 /* 2^-28 */ && span < 1024.0);
     }
     if (c->plan_epoch != ctx->plan_epoch || c->plan_exact != ctx->exact_stop) build_plan(c);
+    // alpha decides whether anything can be handed over at all (alpha_allows_live); when that changes, the postings change
+    // their layout with it: lists of live topics <-> rows of t
+    {
+        const bool off = !alpha_allows_live(ctx, c->live_off_by_alpha);
+        if (off != c->live_off_by_alpha) {
+            c->live_off_by_alpha = off;
+            if (c->have_postings && (c->live_stats || !off)) release_postings(c);
+        }
+    }
     if ((rc = prepare_compact(ctx, c)) != PYLDA_OK) return rc;
     if (!heldout && (rc = build_postings(c)) != PYLDA_OK) return rc;
 

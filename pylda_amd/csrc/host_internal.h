@@ -198,6 +198,7 @@ struct pylda_corpus {
     int32_t* d_col_iters = nullptr;       // D: tile columns x iterations the live-topic kernel executed
     bool compact_ready = false;
     bool compact_failed = false;          // the tile buffer did not fit: dense kernels only, for good
+    bool live_off_by_alpha = false;       // alpha has grown: too many topics never count as dead for any document to be handed over (alpha_allows_live)
     int compact_plan_epoch = -1, compact_cap_used = -1, compact_stream_used = -1, compact_pair_used = -2;
     // schedule ranges of one lane shape (term slots per lane) inside a launch class that hands documents over
     struct CompactRange { int plan_index, slots; bool from_table; int64_t first, count; };
@@ -271,6 +272,9 @@ int launch_qgroup(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int compact_handoff_for(const pylda_ctx* ctx, const Launch& L);      // 0: the class keeps its documents, 1: hands over with tile columns, 2: without
 void compact_caps(const pylda_ctx* ctx, int (&caps)[9]);             // live topics at which a document of s term slots per lane is handed over
 int prepare_compact(pylda_ctx* ctx, pylda_corpus* c);                // buffers and ranges of the hand-over (sets c->compact_ready)
+int immortal_topics(const pylda_ctx* ctx);                           // topics whose alpha keeps them from ever counting as dead (kMortalT), by the host's alpha
+bool alpha_allows_live(const pylda_ctx* ctx, bool was_off);          // fewer of them than the widest tile has columns (with hysteresis)
+void release_postings(pylda_corpus* c);                              // sstats_gather.hip: the next training E-step builds them again
 int launch_compact(pylda_ctx* ctx, const pylda_corpus* c, EstepParams p, int slots, bool from_table, int64_t first, int64_t count);
 
 // ---- sstats_gather.hip ----

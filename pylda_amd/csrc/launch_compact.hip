@@ -1,6 +1,7 @@
 // libpylda_hip.so - the live-topic document kernel (estep_compact.h): hand-over buffers, instantiations and launcher.
 // (host side of the C ABI declared in include/pylda_hip.h; see host_internal.h for the map of the translation units)
 #include "host_internal.h"
+#include <cmath>
 #include "estep_compact.h"
 
 namespace pylda_host {
@@ -63,10 +64,53 @@ void compact_caps(const pylda_ctx* ctx, int (&caps)[9])
     }
 }
 
+// psi(x), x > 0, on the host: recurrence up to 10, then the asymptotic series (the rule below has orders of magnitude to spare)
+static double host_digamma(double x)
+{
+    double shift = 0.0;
+    while (x < 10.0) {
+        shift -= 1.0 / x;
+        x += 1.0;
+    }
+    const double f = 1.0 / (x * x);
+    return shift + std::log(x) - 0.5 / x - f * (1.0 / 12.0 - f * (1.0 / 120.0 - f * (1.0 / 252.0 - f * (1.0 / 240.0 - f * (1.0 / 132.0)))));
+}
+
+// alpha_mortality_kernel's rule (prepare_kernels.h) on the host's copy of alpha: the topics whose t at gamma = alpha is not
+// negligible.  They are live in EVERY document, so they are columns of every tile.  (A topic on the boundary may be classed
+// differently here and on the device: this count only decides whether the hand-over is worth setting up.)
+int immortal_topics(const pylda_ctx* ctx)
+{
+    double sum = 0.0;
+    for (double a : ctx->h_alpha) sum += a;
+    const double psi_shortest = host_digamma(sum + kMortalTokens), bound = std::log(kMortalT);
+    int n = 0;
+    for (double a : ctx->h_alpha) n += !(host_digamma(a) - psi_shortest < bound);
+    return n;
+}
+
+// Once alpha has grown (the Newton update of a training run: cfg 3 past iteration 10, cfg 4 past 18) as many topics never
+// die as the widest tile has columns: no document can leave the dense kernels, and a corpus set up for the hand-over
+// pays for it - the plain walk of the postings adds whole rows for documents without a list (14 ms against the sweep's 8
+// per 200k cfg-4 documents).  From then on the corpus runs as with compact = 0 (and comes back only at half that count).
+bool alpha_allows_live(const pylda_ctx* ctx, bool was_off)
+{
+    if (!ctx->compact || ctx->h_alpha.empty()) return true;
+    int caps[9], widest = 0;
+    compact_caps(ctx, caps);
+    for (int s = 1; s <= 8; ++s) widest = std::max(widest, caps[s]);
+    const int immortal = immortal_topics(ctx);
+    return was_off ? 2 * immortal <= widest : immortal < widest;
+}
+
 int prepare_compact(pylda_ctx* ctx, pylda_corpus* c)
 {
     c->compact_ready = false;
     if (!ctx->compact || c->compact_failed || ctx->exact_stop || ctx->force_logspace || ctx->ldk > 1024) return PYLDA_OK;
+    if (c->live_off_by_alpha) {
+        dev_free(c->d_live_tile);           // (the largest buffer of the corpus: cfg 4 69 GB)
+        return PYLDA_OK;
+    }
     bool any = false;
     for (const Launch& L : c->plan) any = any || compact_handoff_for(ctx, L) > 0;
     if (!any) return PYLDA_OK;

@@ -55,6 +55,18 @@ struct PostingsUndo {
     }
 };
 
+}  // namespace
+
+// (the buffers are idle: hipFree waits for the device)
+void release_postings(pylda_corpus* c)
+{
+    { PostingsUndo undo{c}; }
+    c->have_postings = false;
+    c->live_stats = false;
+}
+
+namespace {
+
 template <typename T>
 int upload(pylda_ctx* ctx, T** dst, const std::vector<T>& src, size_t at_least = 0)
 {

@@ -178,3 +178,37 @@ def test_learning_trace_with_and_without_the_live_topic_kernel(capi):
         vb._ctx.close()
     assert rel_err(np.array(traces[1][0]), np.array(traces[0][0])) < 1e-11
     assert rel_err(traces[1][1], traces[0][1]) < 1e-10
+
+
+def test_alpha_grown_past_the_mortality_bound_switches_the_hand_over_off_and_back(capi):
+    """The alpha update of a training run pushes alpha_k past the bound beyond which a topic never counts as dead
+    (kMortalT); with as many such topics as the widest tile has columns no document can be handed over: the corpus then
+    runs as with compact = 0 - its postings go back to the row layout (the walk over lists would add whole rows per
+    posting) - and returns to the lists when alpha shrinks again.  Same corpus object throughout; the oracle's values in
+    every state."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(21)
+    K, V, D = 128, 2500, 150
+    ptr, ids, cts, eta = topical_corpus(rng, D, V, K, 170)
+    ctx = capi.Context(K, V)
+    corpus = ctx.corpus(ptr, ids, cts)
+    ctx.set_profiling(True)
+    small = np.full(K, 1.0 / K)
+    grown = small.copy()
+    grown[rng.permutation(K)[:70]] = rng.uniform(0.03, 0.3, 70)        # 70 topics that never die: more than any tile holds
+    few = small.copy()
+    few[rng.permutation(K)[:5]] = rng.uniform(0.03, 0.3, 5)            # five: they are columns of every tile, the rest dies
+    for alpha, hands_over in ((small, True), (grown, False), (grown, False), (few, True), (small, True)):
+        ref = c_oracle.e_step(alpha, eta, ptr, ids, cts)
+        ctx.work_counters()
+        out = ctx.estep_host(corpus, alpha, eta)
+        ctx.work_counters()
+        handed = ctx.executed_work()[1]
+        assert (handed > 0.5 * D) if hands_over else handed == 0, handed
+        assert corpus.layout("gather_live") == (1 if hands_over else 0)
+        assert ctx.estep_results(corpus)[2] == 0
+        assert np.array_equal(out["iters"], ref["iters"])
+        assert rel_err(out["gamma"], ref["gamma"]) < GAMMA_RTOL_ORACLE and rel_err(out["doc_ll"], ref["doc_ll"]) < LL_RTOL
+        assert np.max(np.abs(out["sstats"] - ref["sstats"])) < SSTATS_ATOL
+    corpus.close()
+    ctx.close()
