@@ -262,7 +262,9 @@ int pylda_corpus_plan(pylda_corpus* corpus, int32_t capacity, int32_t* variant, 
  * "gather_segments" - its posting segments, "gather_rounds" - the term ranges the gather is run in so that their
  * segments share one set of partial rows, "gather_partial_rows" - those rows, "gather_sweep_passes" - passes of the
  * persistent sweep that replaces rows and rounds (0: not in use), "gather_live" - 1: the pass reads the documents' lists of
- * live topics (sstats_live.h).  Returns the value, or a negative pylda_status. */
+ * live topics (sstats_live.h), "live_off_by_alpha" - 1: alpha keeps more topics from ever dying than a tile of the
+ * live-topic kernel has columns, so the corpus runs on the dense kernels alone (decided before every E-step; when it
+ * changes the postings are rebuilt once in the layout that fits).  Returns the value, or a negative pylda_status. */
 int64_t pylda_corpus_layout(pylda_corpus* corpus, const char* name);
 
 /* Tuning / test options:

@@ -45,6 +45,7 @@ int64_t pylda_corpus_layout(pylda_corpus* c, const char* name)
     if (!strcmp(name, "gather_sweep_passes")) return c->have_postings && c->sweep ? c->sweep_passes : 0;
     if (!strcmp(name, "gather_partial_rows")) return c->have_postings ? c->partial_rows : 0;
     if (!strcmp(name, "gather_live")) return c->have_postings && c->live_stats ? 1 : 0;
+    if (!strcmp(name, "live_off_by_alpha")) return c->live_off_by_alpha ? 1 : 0;
     return fail(c->ctx, PYLDA_ERR_INVALID, "corpus_layout: unknown name '%s'", name);
 }
 

@@ -206,6 +206,7 @@ def test_alpha_grown_past_the_mortality_bound_switches_the_hand_over_off_and_bac
         handed = ctx.executed_work()[1]
         assert (handed > 0.5 * D) if hands_over else handed == 0, handed
         assert corpus.layout("gather_live") == (1 if hands_over else 0)
+        assert corpus.layout("live_off_by_alpha") == (0 if hands_over else 1)
         assert ctx.estep_results(corpus)[2] == 0
         assert np.array_equal(out["iters"], ref["iters"])
         assert rel_err(out["gamma"], ref["gamma"]) < GAMMA_RTOL_ORACLE and rel_err(out["doc_ll"], ref["doc_ll"]) < LL_RTOL
