@@ -164,7 +164,10 @@ __device__ __forceinline__ void quad_hand_over(const EstepParams& p, char* smem,
 // can hide rows only if they stay in registers across it (tried: two or three rows in flight across the gamma phase,
 // consumed at the top of the next iteration in the fused form of estep_qfuse.h; the kernel then spills 150-280 bytes
 // per lane and every reload's vmcnt(0) waits for the rows in flight: 1300 ns per document).
-template <int TL, int RWL, int TWL, int SWL = 0>
+// HANDOFF false: the kernel of the corpora that hand nothing over (option compact = 0; alpha grown past the mortality bound,
+// host_internal.h alpha_allows_live; hand-over buffers that did not fit) - no live count, no exit from the loop: the
+// loop of round 5, whose register allocation the counting perturbs (cfg 4, dense kernels only: 447 -> 4xx ms per E-step).
+template <int TL, int RWL, int TWL, int SWL = 0, bool HANDOFF = true>
 __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepParams p)
 {
     using L = QuadLds<TL, RWL, TWL>;
@@ -437,14 +440,16 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         for (int i = 0; i < C0; ++i) myred[i * RS + cw] = PRE ? lane_group_sum<2>(a[i]) : a[i];
         // ... or the document is handed to the live-topic kernel (estep_compact.h): few enough topics still move
         const bool done = moved <= thresh || left <= 0;                   // :189 (mean <= tol), :174
-        if (done || nlive <= handoff_at) {
+        if (done || (HANDOFF && nlive <= handoff_at)) {
             if constexpr (TWL > 2) lds_row_wait(rowbuf);                  // no read may land after the loop (row 2 is in flight)
             if constexpr (SWL > 1) table_row_wait(sbuf);
             // (the hand-over sits INSIDE the loop, where the tile is alive anyway: behind the loop it would stretch the
             //  tile's live range over the exit paths and the allocator answers by spilling two tile rows in the loop)
-            if (!done && !__syncthreads_or(bad)) {
-                quad_hand_over<TL, RWL, TWL, SWL>(p, smem, B, gam, doc, lo, N, it);
-                return;
+            if constexpr (HANDOFF) {
+                if (!done && !__syncthreads_or(bad)) {
+                    quad_hand_over<TL, RWL, TWL, SWL>(p, smem, B, gam, doc, lo, N, it);
+                    return;
+                }
             }
             break;
         }
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             gpv[ktid] = gam;
             gam = gnew;                                                   // :188
             atomicAdd(&chg[buf], change_fixed(diff));
-            {   // (a padding topic has alpha = gamma = 1 and t = 0: never counted)
+            if constexpr (HANDOFF) {   // (a padding topic has alpha = gamma = 1 and t = 0: never counted)
                 const unsigned long long moving = __ballot(gnew != alpha_k);
                 if (lane == 0) atomicAdd(&livec[buf], (unsigned)__builtin_popcountll(moving));
             }
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
             tt[(buf ^ 1) * KT + ktid] = topic_live ? t_next : 0.0;
             if (ktid == 0) {
                 store_u64_hi(&chg[buf ^ 1], 0u);
-                livec[buf ^ 1] = 0u;
+                if constexpr (HANDOFF) livec[buf ^ 1] = 0u;
             }
         }
         ++it;
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(kWave*(TL / 4), 2) void estep_quad_kernel(EstepPara
         } else {
             moved = (long long)chg[buf];
         }
-        nlive = __builtin_amdgcn_readfirstlane((int)livec[buf]);
+        if constexpr (HANDOFF) nlive = __builtin_amdgcn_readfirstlane((int)livec[buf]);
 #pragma unroll
         for (int jj = 0; jj < KRL / 2; ++jj) {
             const double2 t2 = reinterpret_cast<const double2*>(tt + (buf ^ 1) * KT)[c + TL * jj];

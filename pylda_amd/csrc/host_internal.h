@@ -263,7 +263,8 @@ int launch_generic_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_slab_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_slab_uber_any(pylda_ctx* ctx, const EstepParams& p, const pylda_corpus* c, int from);
 int launch_quilt_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
-int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
+int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);         // (hands on to the next one where the class hands nothing over)
+int launch_quad_dense_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L);   // launch_quad_dense.hip: the kernels without the hand-over
 int launch_qfuse(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_qfusek(pylda_ctx* ctx, const EstepParams& p, const Launch& L);
 int launch_qgroup(pylda_ctx* ctx, const EstepParams& p, const Launch& L);

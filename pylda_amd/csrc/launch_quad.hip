@@ -5,10 +5,17 @@
 
 namespace pylda_host {
 
+#ifndef PYLDA_QUAD_HANDOFF
+#define PYLDA_QUAD_HANDOFF true           // (launch_quad_dense.hip: this file again with false - the kernels of corpora that hand nothing over)
+#define PYLDA_QUAD_LAUNCHER launch_quad_any
+#endif
+
+namespace {     // (internal linkage: this template exists twice in the library, once per value of PYLDA_QUAD_HANDOFF)
+
 template <int TL, int RWL, int TWL, int SWL = 0>
 int launch_quad(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
-    auto kern = estep_quad_kernel<TL, RWL, TWL, SWL>;
+    auto kern = estep_quad_kernel<TL, RWL, TWL, SWL, PYLDA_QUAD_HANDOFF>;
     const size_t lds = QuadLds<TL, RWL, TWL>::total + (size_t)ctx->lds_pad;
     if (lds > 64 * 1024)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -18,8 +25,11 @@ int launch_quad(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
     return PYLDA_OK;
 }
 
-int launch_quad_any(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
+}  // namespace
+
+int PYLDA_QUAD_LAUNCHER(pylda_ctx* ctx, const EstepParams& p, const Launch& L)
 {
+    if (PYLDA_QUAD_HANDOFF && p.handoff_live <= 0) return launch_quad_dense_any(ctx, p, L);
     switch (L.rn) {
     case 160800: return launch_quad<16, 8, 0>(ctx, p, L);
     case 161000: return launch_quad<16, 10, 0>(ctx, p, L);
