@@ -5,7 +5,9 @@
 //   host_plan.cpp      the planner: launch classes, segment cut, rounds, sweep dealing - pure host functions, no HIP
 //   plan.hip           the planner's configuration from the context; pylda_corpus_plan / pylda_corpus_layout
 //   launch_small.hip   document kernels, generic / slab / quilt families
-//   launch_quad.hip    ... the register + LDS tile kernel (strides 128 / 256)
+//   launch_quad.hip    ... the register + LDS tile kernel (strides 128 / 256), handing documents to the live-topic kernel
+//   launch_quad_dense.hip  ... the same without the hand-over (launch_quad.hip compiled again with the flag off)
+//   launch_compact.hip ... the live-topic kernel behind them, its buffers, and whether alpha still lets topics die
 //   launch_stream.hip  ... the fused streaming families (qfuse, qfusek, qgroup)
 //   sstats_gather.hip  postings, segments and the statistics pass (dispatch-paced gather, persistent sweep)
 //   estep_api.hip      corpus upload, pylda_estep and its read-backs
