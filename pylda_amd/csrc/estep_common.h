@@ -50,7 +50,7 @@ struct EstepParams {
     int tile_from_table;      // live-topic kernel: 1: the launch's documents have no tile in live_tile - gather it from the table
     int32_t* live_n;          // D: live topics of a document handed over (status 4); after the E-step: entries of its list of t
                               //    (live_stats), -1: the document's t is the dense row tfinal[d]
-    char* live_list;          // D x kLiveListBytes: topic indices (uint16 x kLiveStride), then t of the last iteration (double x kLiveStride)
+    char* live_list;          // D x kLiveListBytes: a document's live topics and their t of the last iteration (layout below)
     int live_stats;           // 1: the statistics pass reads the lists (sstats_live.h): the live-topic kernel writes no dense row
     double* live_tile;        // the document's compact tile: value of term n, live topic j at live_tile[tile_ptr[d] + j * N_d + n]
     const int64_t* tile_ptr;  // D offsets into live_tile (doubles)
@@ -83,24 +83,24 @@ constexpr double kMortalT = 1e-33;
 constexpr double kMortalTokens = 8.0;
 
 constexpr int kLiveStride = 60;   // entries per document's list: the largest live set the live-topic kernel takes over
-// A document's list of live topics (EstepParams::live_list), 640 bytes = five 128-byte lines:
-//     line 0        t[0 .. 12) (96 bytes), then topic[0 .. 12) as uint16 (24 bytes)
-//     lines 1-3     t[12 .. 60)
-//     line 4        topic[12 .. 60)
-// The statistics pass reads a document's list once per posting, at random over the corpus: nineteen in twenty documents
-// finish with at most twelve live topics (cfg 4: seven on average) and cost it ONE line.
+// A document's list of live topics (EstepParams::live_list), 640 bytes = five 128-byte lines of twelve entries each:
+//     line l        t[12 l .. 12 l + 12) (96 bytes), then topic[12 l .. 12 l + 12) as uint16 (24 bytes)
+// The statistics pass reads a document's list once per posting, at random over the corpus: a document that finishes with
+// at most twelve live topics costs it ONE line (cfg 4 after three outer iterations: nineteen documents in twenty), up to
+// twenty-four TWO (the rule from outer iteration five on: the trained model's documents use more topics; with the tail
+// of the list split into a t part and a topic part they cost three, and the pass 17-19 ms instead of 12.8).
 constexpr int kLiveHead = 12;
 constexpr int kLiveListBytes = 640;
 __device__ __forceinline__ double* live_t_at(char* list, int j)
 {
-    return reinterpret_cast<double*>(list + (j < kLiveHead ? 8 * j : 128 + 8 * (j - kLiveHead)));
+    return reinterpret_cast<double*>(list + 128 * (j / kLiveHead) + 8 * (j % kLiveHead));
 }
 __device__ __forceinline__ uint16_t* live_idx_at(char* list, int j)
 {
-    return reinterpret_cast<uint16_t*>(list + (j < kLiveHead ? 96 + 2 * j : 512 + 2 * (j - kLiveHead)));
+    return reinterpret_cast<uint16_t*>(list + 128 * (j / kLiveHead) + 96 + 2 * (j % kLiveHead));
 }
 __device__ __forceinline__ char* live_list_of(char* live_list, int64_t doc) { return live_list + doc * kLiveListBytes; }
-static_assert(128 + 8 * (kLiveStride - kLiveHead) == 512 && 512 + 2 * (kLiveStride - kLiveHead) <= kLiveListBytes, "list layout");
+static_assert(kLiveStride % kLiveHead == 0 && 128 * (kLiveStride / kLiveHead) == kLiveListBytes && 10 * kLiveHead <= 128, "list layout");
 
 // Sum over the 64 lanes, result in every lane, without the LDS crossbar (ds_bpermute costs an LDS
 // round trip per level): four DPP levels inside each 16-lane row, then one permlane16 and one

@@ -3,7 +3,7 @@
 // sstats_kernels.h / sstats_sweep.h gather, per posting (term w, document d), the document's whole row t_d[0 .. ldk):
 // 2 KiB at K = 256 of which - once the live-topic kernel (estep_compact.h) has finished the document - all but a
 // dozen entries are exactly the dead topics' 1e-114, i.e. nothing a statistic can see (eta = statistics + beta).  Those
-// documents now leave a list: up to 60 (topic, t) pairs, the first twelve in ONE 128-byte line (estep_common.h), and this pass adds
+// documents now leave a list: up to 60 (topic, t) pairs, twelve to a 128-byte line (estep_common.h), and this pass adds
 //
 //     acc[w][k_j] += r_dw t_dj        for the entries j of the list of d
 //
