@@ -1,5 +1,5 @@
-"""E-steps of the bench's timed window alone, for a profiler: python tools/estep_only.py cfg3|cfg4 [docs] [esteps] [name=value ...] [max_iter=N]
-(3 learning() iterations from the seeded start, then `esteps` training E-steps of the next outer iteration, fast path)."""
+"""E-steps of the bench's timed window alone, for a profiler: python tools/estep_only.py cfg3|cfg4 [docs] [esteps] [name=value ...] [max_iter=N] [outer=N]
+(`outer` learning() iterations - default 3 - from the seeded start, then `esteps` training E-steps of the next outer iteration, fast path)."""
 import os
 import sys
 
@@ -24,14 +24,16 @@ vb = VariationalBayes(hyper_parameter_optimize_interval=1, device=0)
 vb._verbose = False
 vb._initialize_parsed(ptr, ids, cts, V, K, 1.0 / K, 1.0 / V, eta=eta0)
 ctx = vb._context()
-max_iter = 50
+max_iter, outer = 50, 3
 for opt in sys.argv[4:]:
     k, v = opt.split("=")
-    if k == "max_iter":         # (the timed E-steps only: the model is the one three full learning() iterations leave)
+    if k == "max_iter":         # (the timed E-steps only: the model is the one the full learning() iterations leave)
         max_iter = int(v)
+    elif k == "outer":          # learning() iterations before the timed E-steps (default 3: the bench's window starts there)
+        outer = int(v)
     else:
         ctx.set_option(k, int(v))
-for _ in range(3):
+for _ in range(outer):
     vb.learning()
 vb._push_model()
 corpus = vb._train_corpus
